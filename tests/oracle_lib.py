@@ -1,0 +1,244 @@
+"""ctypes binding of oracle/liborb_oracle.so (the CPU checker; test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int32)
+f32p = C.POINTER(C.c_float)
+i64p = C.POINTER(C.c_int64)
+
+
+class OracleParams(C.Structure):
+    _fields_ = [
+        ("nfeatures", C.c_int),
+        ("scale_factor", C.c_float),
+        ("nlevels", C.c_int),
+        ("threshold", C.c_int),
+        ("n", C.c_int),
+        ("nms_window", C.c_int),
+        ("patch_size", C.c_int),
+        ("harris_window", C.c_int),
+        ("harris_k", C.c_float),
+        ("blur_levels", C.c_int),
+        ("blur_kind", C.c_int),
+    ]
+
+
+def gpu_params(nfeatures=500, scale_factor=1.2, nlevels=8, threshold=20, n=9, nms_window=3, patch_size=31,
+               harris_window=7, harris_k=0.04, blur_levels=0, blur_kind=0):
+    return OracleParams(nfeatures, scale_factor, nlevels, threshold, n, nms_window, patch_size, harris_window,
+                        harris_k, blur_levels, blur_kind)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(ROOT, "oracle", "liborb_oracle.so")
+        src = os.path.join(ROOT, "oracle", "orb_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+        _LIB = C.CDLL(so)
+        _LIB.oracle_level_scale.restype = C.c_float
+        _LIB.oracle_level_scale.argtypes = [C.c_float, C.c_int]
+        _LIB.oracle_level_quota.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int]
+        _LIB.oracle_level_size.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _LIB.oracle_gaussian_kernel.argtypes = [C.c_int, C.c_float, f32p]
+        _LIB.oracle_harris.argtypes = [u8p, C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.c_int, C.c_float, f32p]
+    return _LIB
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(u8p)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def fast_score(img, threshold, n=9):
+    img, ip = _u8(img)
+    h, w = img.shape
+    scores = np.empty((h, w), np.float32)
+    npre, ncor = C.c_int64(0), C.c_int64(0)
+    lib().oracle_fast_score(ip, w, h, w, threshold, n, _p(scores, f32p), C.byref(npre), C.byref(ncor))
+    return scores, npre.value, ncor.value
+
+
+def nms(scores, nms_window, nfeatures):
+    scores = np.ascontiguousarray(scores, np.float32)
+    h, w = scores.shape
+    kps = np.zeros((max(nfeatures, 1), 2), np.int32)
+    tot = C.c_int64(0)
+    c = lib().oracle_nms(_p(scores, f32p), w, h, nms_window, nfeatures, _p(kps, i32p), C.byref(tot))
+    return kps[:c].copy(), tot.value
+
+
+def fast_detect(img, threshold, n, nms_window, nfeatures):
+    img, ip = _u8(img)
+    h, w = img.shape
+    kps = np.zeros((max(nfeatures, 1), 2), np.int32)
+    c = lib().oracle_fast_detect(ip, w, h, w, threshold, n, nms_window, nfeatures, _p(kps, i32p))
+    return kps[:c].copy()
+
+
+def orientations(img, kps, patch_size):
+    img, ip = _u8(img)
+    h, w = img.shape
+    kps = np.ascontiguousarray(kps, np.int32).reshape(-1, 2)
+    ang = np.zeros(len(kps), np.float32)
+    lib().oracle_orientations(ip, w, h, w, _p(kps, i32p), len(kps), patch_size, _p(ang, f32p))
+    return ang
+
+
+def brief(img, kps, angles):
+    img, ip = _u8(img)
+    h, w = img.shape
+    kps = np.ascontiguousarray(kps, np.int32).reshape(-1, 2)
+    angles = np.ascontiguousarray(angles, np.float32)
+    n = len(kps)
+    desc = np.zeros((n, 32), np.uint8)
+    valid = np.zeros((n, 32), np.uint8)
+    nskip, noob = C.c_int64(0), C.c_int64(0)
+    lib().oracle_brief(ip, w, h, w, _p(kps, i32p), _p(angles, f32p), n, _p(desc, u8p), _p(valid, u8p),
+                       C.byref(nskip), C.byref(noob))
+    return desc, valid, nskip.value, noob.value
+
+
+def detect_and_compute_cpu(img, nfeatures=3000, threshold=50, n=9, nms_window=3, patch_size=9):
+    """ORBCPU::detectAndCompute with the OrientedFASTCPU defaults (orb_cpu.hpp:6)."""
+    img, ip = _u8(img)
+    h, w = img.shape
+    kps = np.zeros((max(nfeatures, 1), 2), np.int32)
+    ang = np.zeros(max(nfeatures, 1), np.float32)
+    desc = np.zeros((max(nfeatures, 1), 32), np.uint8)
+    valid = np.zeros((max(nfeatures, 1), 32), np.uint8)
+    c = lib().oracle_detect_and_compute_cpu(ip, w, h, w, nfeatures, threshold, n, nms_window, patch_size,
+                                            _p(kps, i32p), _p(ang, f32p), _p(desc, u8p), _p(valid, u8p))
+    return kps[:c].copy(), ang[:c].copy(), desc[:c].copy(), valid[:c].copy()
+
+
+def blur5_sep(img):
+    img, ip = _u8(img)
+    h, w = img.shape
+    out = np.empty_like(img)
+    lib().oracle_blur5_sep(ip, w, h, w, _p(out, u8p), w)
+    return out
+
+
+def blur5_273(img):
+    img, ip = _u8(img)
+    h, w = img.shape
+    out = np.empty_like(img)
+    lib().oracle_blur5_273(ip, w, h, w, _p(out, u8p), w)
+    return out
+
+
+def gaussian_kernel(K, sigma=-1.0):
+    k = np.zeros(K * K, np.float32)
+    lib().oracle_gaussian_kernel(K, sigma, _p(k, f32p))
+    return k.reshape(K, K)
+
+
+def conv2d_u8(padded, kernel):
+    padded, ip = _u8(padded)
+    h, w = padded.shape
+    kernel = np.ascontiguousarray(kernel, np.float32)
+    K = kernel.shape[0]
+    out = np.empty((h - K + 1, w - K + 1), np.uint8)
+    lib().oracle_conv2d_u8(ip, w, h, w, _p(kernel, f32p), K, _p(out, u8p))
+    return out
+
+
+def gaussian_blur_conv(img, K):
+    img, ip = _u8(img)
+    h, w = img.shape
+    out = np.empty_like(img)
+    lib().oracle_gaussian_blur_conv(ip, w, h, w, K, _p(out, u8p))
+    return out
+
+
+def sobel_u8(img, direction):
+    img, ip = _u8(img)
+    h, w = img.shape
+    out = np.empty_like(img)
+    lib().oracle_sobel_u8(ip, w, h, w, direction, _p(out, u8p))
+    return out
+
+
+def harris(img, kps, window=7, k=0.04):
+    img, ip = _u8(img)
+    h, w = img.shape
+    kps = np.ascontiguousarray(kps, np.int32).reshape(-1, 2)
+    out = np.zeros(len(kps), np.float32)
+    lib().oracle_harris(ip, w, h, w, _p(kps, i32p), len(kps), window, k, _p(out, f32p))
+    return out
+
+
+def level_size(w0, h0, scale_factor, level):
+    wl, hl = C.c_int(0), C.c_int(0)
+    lib().oracle_level_size(w0, h0, scale_factor, level, C.byref(wl), C.byref(hl))
+    return wl.value, hl.value
+
+
+def level_quota(nfeatures, scale_factor, nlevels, level):
+    return lib().oracle_level_quota(nfeatures, scale_factor, nlevels, level)
+
+
+def level_scale(scale_factor, level):
+    return lib().oracle_level_scale(scale_factor, level)
+
+
+def resize_linear(img, dw, dh):
+    img, ip = _u8(img)
+    h, w = img.shape
+    out = np.empty((dh, dw), np.uint8)
+    lib().oracle_resize_linear(ip, w, h, w, _p(out, u8p), dw, dh, dw)
+    return out
+
+
+def select_top(resp, keep):
+    resp = np.ascontiguousarray(resp, np.float32)
+    idx = np.zeros(max(len(resp), 1), np.int32)
+    m = lib().oracle_select_top(_p(resp, f32p), len(resp), keep, _p(idx, i32p))
+    return idx[:m].copy()
+
+
+def build_level(img, params, level):
+    img, ip = _u8(img)
+    h, w = img.shape
+    wl, hl = level_size(w, h, params.scale_factor, level)
+    out = np.empty((hl, wl), np.uint8)
+    lib().oracle_build_level(ip, w, h, w, C.byref(params), level, _p(out, u8p))
+    return out
+
+
+def detect_and_compute_gpu(img, params):
+    """ORB::detectAndCompute (orb.cpp:58-109 intent). Returns dict of arrays."""
+    img, ip = _u8(img)
+    h, w = img.shape
+    cap = sum(level_quota(params.nfeatures, params.scale_factor, params.nlevels, l) for l in range(params.nlevels))
+    cap = max(cap, 1)
+    kps = np.zeros((cap, 2), np.int32)
+    kpl = np.zeros((cap, 2), np.int32)
+    lev = np.zeros(cap, np.int32)
+    ang = np.zeros(cap, np.float32)
+    resp = np.zeros(cap, np.float32)
+    desc = np.zeros((cap, 32), np.uint8)
+    valid = np.zeros((cap, 32), np.uint8)
+    c = lib().oracle_detect_and_compute_gpu(ip, w, h, w, C.byref(params), _p(kps, i32p), _p(kpl, i32p),
+                                            _p(lev, i32p), _p(ang, f32p), _p(resp, f32p), _p(desc, u8p),
+                                            _p(valid, u8p), cap)
+    return dict(kps=kps[:c].copy(), kps_level=kpl[:c].copy(), levels=lev[:c].copy(), angles=ang[:c].copy(),
+                responses=resp[:c].copy(), desc=desc[:c].copy(), valid=valid[:c].copy())
+
+
+def load_kitti(i=0):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "kitti_%06d.npz" % i))
+    return z["image"]
