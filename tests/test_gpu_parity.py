@@ -1,0 +1,287 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on
+the same inputs.  Bar: bit-exact for keypoints, masks, u8 images and
+descriptors; 1e-4 for angles (they are in fact bit-equal) and 1e-4 relative
+for Harris responses.
+
+Run on the GPU box with:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def synth(seed, h, w, kind="rects"):
+    """Seeded synthetic frame with KITTI-like statistics (stream B, simplified)."""
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img = np.full((h, w), 89.0)
+    img += 25.0 * rng.standard_normal((h, w))
+    for _ in range(max(8, h * w // 1500)):
+        x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+        ww, hh = int(rng.integers(3, 40)), int(rng.integers(3, 40))
+        img[y0:y0 + hh, x0:x0 + ww] += rng.uniform(20, 120) * rng.choice([-1, 1])
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+@pytest.fixture(scope="module")
+def kitti0():
+    return O.load_kitti(0)
+
+
+@pytest.fixture(scope="module")
+def kitti1():
+    return O.load_kitti(1)
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    p = pkg.default_params("gpu", max_width=1920, max_height=1080, max_batch=4)
+    c = pkg.Context(p)
+    yield c
+    c.close()
+
+
+# ---------------------------------------------------------------------------
+# stage operators
+
+
+@pytest.mark.parametrize("threshold,n", [(50, 9), (20, 9), (20, 12), (35, 16), (10, 1), (0, 9)])
+def test_fast_score_map_kitti(ctx, kitti0, threshold, n):
+    ref, _, ncor = O.fast_score(kitti0, threshold, n)
+    got = ctx.fast_score(kitti0, threshold, n)
+    assert np.array_equal(got, ref)
+    assert int((got > 0).sum()) <= ncor  # corners with score 0 cannot exist for threshold > 0
+    if threshold > 0:
+        assert int((got > 0).sum()) == ncor
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (9, 71), (64, 64), (65, 129), (120, 160), (33, 700), (200, 63)])
+def test_fast_score_map_shapes(ctx, shape):
+    for kind in ("rects", "noise"):
+        img = synth(hash(shape) % 1000, shape[0], shape[1], kind)
+        ref, _, _ = O.fast_score(img, 20, 9)
+        assert np.array_equal(ctx.fast_score(img, 20, 9), ref), (shape, kind)
+
+
+@pytest.mark.parametrize("threshold,nms_window,nfeatures", [(50, 3, 3000), (20, 3, 3000), (20, 3, 434), (20, 0, 5000),
+                                                            (20, 5, 3000), (20, 7, 3000), (50, 3, 0), (50, 3, 1)])
+def test_fast_detect_kitti(ctx, kitti0, threshold, nms_window, nfeatures):
+    """Fast() == OrientedFASTCPU::detect: ordered, capped keypoints bit-exact."""
+    scores, _, _ = O.fast_score(kitti0, threshold, 9)
+    ref, tot = O.nms(scores, nms_window, nfeatures)
+    got, gtot = ctx.fast(kitti0, threshold, 9, nms_window, nfeatures)
+    assert gtot == tot
+    assert np.array_equal(got, ref)
+
+
+def test_nms_stage_on_score_map(ctx, kitti1):
+    scores, _, _ = O.fast_score(kitti1, 20, 9)
+    for win in (3, 5):
+        ref, tot = O.nms(scores, win, 100000)
+        got, gtot = ctx.nms(scores, win, 100000, 0.0)
+        assert gtot == tot and np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("patch", [9, 31, 1, 41])
+def test_orientations(ctx, kitti0, patch):
+    kps = O.fast_detect(kitti0, 20, 9, 3, 3000)
+    ref = O.orientations(kitti0, kps, patch)
+    got = ctx.orientations(kitti0, kps, patch)
+    assert np.allclose(got, ref, atol=1e-4, rtol=0)
+    # the restated glibc atan2f makes them bit-identical, not merely close
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert int((ref == 0).sum()) == int((got == 0).sum())
+
+
+def test_brief_given_angles(ctx, kitti0):
+    kps = O.fast_detect(kitti0, 50, 9, 3, 3000)
+    ang = O.orientations(kitti0, kps, 9)
+    ref, valid, nskip, noob = O.brief(kitti0, kps, ang)
+    got = ctx.brief(kitti0, kps, ang)
+    assert nskip == 3220
+    assert np.array_equal(got & valid, ref & valid)
+    # the zero-extension rule makes even the D15 bits agree with the restatement
+    assert np.array_equal(got, ref)
+
+
+def test_brief_random_angles_and_border_keypoints(ctx):
+    img = synth(7, 90, 130, "noise")
+    rng = np.random.default_rng(3)
+    kps = np.stack([rng.integers(0, 130, 600), rng.integers(0, 90, 600)], 1).astype(np.int32)
+    ang = rng.uniform(-np.pi, np.pi, 600).astype(np.float32)
+    ang[:8] = [0.0, np.pi, -np.pi, np.pi / 2, -np.pi / 2, np.pi / 4, 1e-30, -0.0]
+    ref, valid, _, _ = O.brief(img, kps, ang)
+    got = ctx.brief(img, kps, ang)
+    assert np.array_equal(got, ref)
+
+
+def test_harris(ctx, kitti0):
+    kps = O.fast_detect(kitti0, 20, 9, 3, 1500)
+    ref = O.harris(kitti0, kps, 7, 0.04)
+    got = ctx.harris(kitti0, kps, 7, 0.04)
+    assert np.allclose(got, ref, rtol=1e-4, atol=1e-2)
+    assert np.array_equal(got, ref)  # same operation order, no contraction: identical
+    # near-border keypoints exercise REFLECT_101 of the Sobel taps
+    edge = np.array([[0, 0], [1, 1], [3, 3], [1240, 375], [1237, 372], [0, 200], [1240, 5]], np.int32)
+    assert np.array_equal(ctx.harris(kitti0, edge, 7, 0.04), O.harris(kitti0, edge, 7, 0.04))
+    for win in (3, 5):
+        assert np.array_equal(ctx.harris(kitti0, kps[:200], win, 0.06), O.harris(kitti0, kps[:200], win, 0.06))
+
+
+@pytest.mark.parametrize("shape", [(376, 1241), (8, 8), (17, 65), (64, 64), (100, 130), (33, 257)])
+def test_blur_stages(ctx, kitti0, shape):
+    img = kitti0 if shape == (376, 1241) else synth(shape[1], shape[0], shape[1], "noise")
+    assert np.array_equal(ctx.blur5_sep(img), O.blur5_sep(img))
+    assert np.array_equal(ctx.blur5_273(img), O.blur5_273(img))
+
+
+def test_conv_sobel_gaussian(ctx, pkg, kitti0):
+    img = kitti0[:200, :333].copy()
+    for K in (3, 5, 7):
+        assert np.array_equal(pkg.orbx.gaussian_kernel(K), O.gaussian_kernel(K))
+        assert np.array_equal(ctx.gaussian_blur_conv(img, K), O.gaussian_blur_conv(img, K))
+    for d in (0, 1):
+        assert np.array_equal(ctx.sobel(img, d), O.sobel_u8(img, d))
+    kern = np.random.default_rng(0).uniform(-0.2, 0.4, (5, 5)).astype(np.float32)
+    assert np.array_equal(ctx.conv2d(img, kern), O.conv2d_u8(img, kern))
+
+
+def test_select_top(ctx):
+    rng = np.random.default_rng(5)
+    r = rng.standard_normal(1000).astype(np.float32)
+    r[100:130] = r[5]  # ties must resolve by index
+    for keep in (0, 1, 217, 1000, 2000):
+        assert np.array_equal(ctx.select_top(r, keep), O.select_top(r, keep))
+
+
+# ---------------------------------------------------------------------------
+# pyramid
+
+
+@pytest.mark.parametrize("blur_levels,blur_kind", [(0, 0), (1, 0), (2, 0), (2, 1)])
+def test_pyramid_levels(pkg, kitti0, blur_levels, blur_kind):
+    p = pkg.default_params("gpu", max_width=1241, max_height=376, blur_levels=blur_levels, blur_kind=blur_kind)
+    op = O.gpu_params(blur_levels=blur_levels, blur_kind=blur_kind)
+    with pkg.Context(p) as c:
+        pl = c.plan(1241, 376)
+        assert list(pl["level_w"]) == [1241, 1034, 862, 718, 598, 499, 416, 346]
+        assert list(pl["level_h"]) == [376, 313, 261, 218, 181, 151, 126, 105]
+        for l in range(8):
+            assert np.array_equal(c.build_pyramid_level(kitti0, l), O.build_level(kitti0, op, l)), l
+
+
+# ---------------------------------------------------------------------------
+# whole path
+
+
+def check_whole(got, ref):
+    assert got["count"] == len(ref["kps"])
+    assert np.array_equal(got["kps"], ref["kps"])
+    assert np.array_equal(got["kps_level"], ref["kps_level"])
+    assert np.array_equal(got["levels"], ref["levels"])
+    assert np.allclose(got["angles"], ref["angles"], atol=1e-4, rtol=0)
+    assert np.allclose(got["responses"], ref["responses"], rtol=1e-4, atol=1e-2)
+    assert np.array_equal(got["desc"] & ref["valid"], ref["desc"] & ref["valid"])
+
+
+def test_cpu_flavour_config0(pkg, kitti0):
+    """BASELINE.json configs[0]: orb_cpu.cpp detectAndCompute on 000000.png, one level."""
+    p = pkg.default_params("cpu", max_width=1241, max_height=376)
+    with pkg.Context(p) as c:
+        got = c.detect_and_compute(kitti0)
+    kps, ang, desc, valid = O.detect_and_compute_cpu(kitti0)
+    assert got["count"] == 1178 == len(kps)  # SURVEY.md §7 known answer
+    assert np.array_equal(got["kps"], kps)
+    assert tuple(got["kps"][0]) == (815, 3) and tuple(got["kps"][-1]) == (25, 366)
+    assert np.array_equal(got["angles"].view(np.uint32), ang.view(np.uint32))
+    assert int((got["angles"] == 0).sum()) == 3
+    assert np.array_equal(got["desc"] & valid, desc & valid)
+    assert np.array_equal(got["desc"], desc)
+    assert np.all(got["levels"] == 0) and np.all(got["responses"] == 0)
+
+
+@pytest.mark.parametrize("blur_levels", [0, 2])
+def test_gpu_flavour_config1(pkg, kitti0, kitti1, blur_levels):
+    """BASELINE.json configs[1]: 1241x376, 8 levels, scale 1.2, 1000 features."""
+    p = pkg.default_params("gpu", nfeatures=1000, max_width=1241, max_height=376, blur_levels=blur_levels)
+    op = O.gpu_params(nfeatures=1000, blur_levels=blur_levels)
+    with pkg.Context(p) as c:
+        pl = c.plan(1241, 376)
+        assert list(pl["quota"]) == [217, 180, 150, 125, 104, 87, 72, 60]
+        for img in (kitti0, kitti1):
+            check_whole(c.detect_and_compute(img), O.detect_and_compute_gpu(img, op))
+
+
+def test_gpu_flavour_config4_1080p(pkg):
+    """BASELINE.json configs[4]: 1920x1080, 12 levels, 4000 keypoints, Harris + NMS."""
+    img = synth(11, 1080, 1920)
+    p = pkg.default_params("gpu", nfeatures=4000, nlevels=12, max_width=1920, max_height=1080, blur_levels=2)
+    op = O.gpu_params(nfeatures=4000, nlevels=12, blur_levels=2)
+    with pkg.Context(p) as c:
+        pl = c.plan(1920, 1080)
+        assert list(pl["quota"]) == [750, 625, 521, 434, 362, 301, 251, 209, 174, 145, 121, 101]
+        check_whole(c.detect_and_compute(img), O.detect_and_compute_gpu(img, op))
+
+
+@pytest.mark.parametrize("kw", [dict(threshold=20, n=12), dict(threshold=35, nms_window=5), dict(nms_window=0, nfeatures=200),
+                                dict(patch_size=9, nlevels=3, scale_factor=1.5), dict(blur_levels=1), dict(blur_levels=2, blur_kind=1),
+                                dict(harris_window=5, harris_k=0.06)])
+def test_gpu_flavour_param_sweep(pkg, kw):
+    img = synth(21, 120, 160)
+    base = dict(nfeatures=300, nlevels=6)
+    base.update(kw)
+    p = pkg.default_params("gpu", max_width=160, max_height=120, **base)
+    with pkg.Context(p) as c:
+        check_whole(c.detect_and_compute(img), O.detect_and_compute_gpu(img, O.gpu_params(**base)))
+
+
+def test_batch_matches_single_and_device_path(pkg, kitti0, kitti1):
+    """Batched device-resident path == per-frame host path == oracle; ragged frame content."""
+    import torch
+
+    frames = np.stack([kitti0, kitti1, np.zeros_like(kitti0), np.roll(kitti0, (5, 9), (0, 1))])
+    p = pkg.default_params("gpu", nfeatures=1000, max_width=1241, max_height=376, max_batch=4, blur_levels=2)
+    op = O.gpu_params(nfeatures=1000, blur_levels=2)
+    with pkg.Context(p) as c:
+        cap = c.plan(1241, 376)["out_capacity"]
+        t = torch.from_numpy(frames).cuda()
+        torch.cuda.synchronize()
+        c.batch_device(t.data_ptr(), 4, 1241, 376)
+        dev = c.batch_fetch(0, 4, cap)
+        c.batch_host(frames)
+        host = c.batch_fetch(0, 4, cap)
+        for k in ("counts", "kps", "angles", "desc", "levels", "responses"):
+            assert np.array_equal(dev[k], host[k]), k
+        assert dev["counts"][2] == 0  # empty frame: no keypoints, no crash
+        for i in range(4):
+            ref = O.detect_and_compute_gpu(frames[i], op)
+            n = int(dev["counts"][i])
+            got = dict(count=n, kps=dev["kps"][i, :n], kps_level=dev["kps_level"][i, :n], levels=dev["levels"][i, :n],
+                       angles=dev["angles"][i, :n], responses=dev["responses"][i, :n], desc=dev["desc"][i, :n])
+            check_whole(got, ref)
+
+
+def test_frame_size_change_and_capacity_error(pkg, kitti0):
+    p = pkg.default_params("gpu", nfeatures=500, max_width=1241, max_height=376)
+    op = O.gpu_params(nfeatures=500)
+    with pkg.Context(p) as c:
+        for sl in ((slice(0, 376), slice(0, 1241)), (slice(10, 200), slice(100, 900)), (slice(0, 376), slice(0, 1241))):
+            img = np.ascontiguousarray(kitti0[sl])
+            check_whole(c.detect_and_compute(img), O.detect_and_compute_gpu(img, op))
+        got = c.detect_and_compute(kitti0, capacity=10)
+        assert got["status"] == pkg.orbx.ERR_CAPACITY and got["count"] > 10 and len(got["kps"]) == 10
+        with pytest.raises(pkg.OrbxError):
+            c.detect_and_compute(np.zeros((400, 1300), np.uint8))  # larger than max_width/max_height
+
+
+def test_error_paths(pkg):
+    with pytest.raises(pkg.OrbxError):
+        pkg.Context(pkg.default_params("gpu", nlevels=40))
+    with pytest.raises(pkg.OrbxError):
+        pkg.Context(pkg.default_params("gpu", n=17))
+    with pytest.raises(pkg.OrbxError):  # level 15 of a 64x64 frame is < 8x8
+        pkg.Context(pkg.default_params("gpu", nlevels=16, max_width=64, max_height=64))

@@ -1,0 +1,1025 @@
+// orbx_api.cpp -- C-ABI host layer of liborbx.so (see include/orbx.h).
+//
+// Owns the context (device memory pools, stream, per-size plan), validates
+// arguments, sequences the kernel launches of orbx_kernels.hip and moves
+// results.  There is NO CPU fallback anywhere in this file: if the HIP
+// runtime or a gfx950 device is missing every entry point fails loudly with
+// ORBX_ERR_NO_DEVICE / ORBX_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "orbx_internal.h"
+
+hipError_t orbx_launch_harris_flat(hipStream_t s, const uint8_t* d_img, int w, int h, int pitch,
+                                   const orbx_keypoint* d_kps, int nkp, const float* d_gauss, int K, float kk,
+                                   float* d_resp);
+
+namespace {
+
+thread_local std::string g_create_error;
+
+inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+inline size_t align_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+// result block of a batch: one device allocation + one pinned host mirror so
+// a whole batch comes back with a single D2H copy
+struct OutLayout {
+  size_t counts, kp, lkp, angle, resp, level, desc, total;
+};
+
+OutLayout make_out_layout(int n, int cap) {
+  OutLayout o;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t r = off;
+    off = align_up_sz(off + bytes, 256);
+    return r;
+  };
+  const size_t e = (size_t)n * (size_t)cap;
+  o.counts = take(sizeof(int32_t) * (size_t)n);
+  o.kp = take(sizeof(orbx_keypoint) * e);
+  o.lkp = take(sizeof(orbx_keypoint) * e);
+  o.angle = take(sizeof(float) * e);
+  o.resp = take(sizeof(float) * e);
+  o.level = take(sizeof(int32_t) * e);
+  o.desc = take(sizeof(orbx_descriptor) * e);
+  o.total = off;
+  return o;
+}
+
+}  // namespace
+
+struct orbx_ctx {
+  orbx_params p{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // geometry for the current frame size, and for the largest size (capacity)
+  OrbxPlan plan{};
+  OrbxPlan plan_max{};
+  OrbxTileMap tm_pyr{}, tm_blur{}, tm_fast{};
+  std::vector<OrbxResizeTap> h_taps;
+  int plan_w = 0, plan_h = 0;
+
+  // pools (sized for max_batch frames of max_width x max_height)
+  uint8_t* d_in = nullptr;  // staged host frames, tight pitch
+  uint8_t* d_pyr = nullptr;
+  uint8_t* d_pyr_blur = nullptr;
+  unsigned long long* d_mask = nullptr;
+  orbx_keypoint* d_cand = nullptr;
+  int32_t* d_cand_count = nullptr;
+  int32_t* d_cand_total = nullptr;
+  float* d_resp = nullptr;
+  OrbxResizeTap* d_taps = nullptr;
+  size_t taps_capacity = 0;
+  float* d_gauss = nullptr;
+  uint8_t* d_out = nullptr;
+  uint8_t* h_out = nullptr;  // pinned mirror
+  OutLayout out_layout{};
+  int out_cap = 0;  // slot capacity of the pool (plan_max.out_cap)
+  int last_n = 0;
+  hipStream_t last_stream = nullptr;
+
+  // stage-API scratch (grown on demand; never touched by the batched path)
+  DevBuf s_img_a, s_img_b, s_f32, s_u16, s_mask, s_kps, s_f32b, s_desc, s_i32, s_kern;
+
+  bool timing = false;
+  hipEvent_t ev[ORBX_NUM_STAGE_TIMES + 1] = {};
+  bool ev_valid = false;
+  float last_ms[ORBX_NUM_STAGE_TIMES] = {};
+};
+
+namespace {
+
+int fail(orbx_ctx* c, int status, const std::string& msg) {
+  if (c)
+    c->err = msg;
+  else
+    g_create_error = msg;
+  return status;
+}
+
+#define HIPCHK(c, expr)                                                                              \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess)                                                                            \
+      return fail((c), ORBX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+  } while (0)
+
+int ensure(orbx_ctx* c, DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes && b.p) return ORBX_OK;
+  if (b.p) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  bytes = align_up_sz(std::max<size_t>(bytes, 256), 256);
+  HIPCHK(c, hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return ORBX_OK;
+}
+
+// ---- geometry (src/orb.cpp:62, :95, :117-118) ------------------------------
+
+float level_scale(float sf, int l) { return (float)std::pow((double)sf, (double)l); }
+
+void level_size(int w0, int h0, float sf, int l, int* wl, int* hl) {
+  if (l == 0) {
+    *wl = w0;
+    *hl = h0;
+    return;
+  }
+  const float scale = level_scale(sf, l);
+  *wl = (int)std::round((double)((float)w0 / scale));
+  *hl = (int)std::round((double)((float)h0 / scale));
+}
+
+int level_quota(int nfeatures, float sf, int nlevels, int l) {
+  // int * ((float - float) / (int - double)) * double, truncated to int
+  const float inv = 1 / sf;
+  const float num = 1 - inv;
+  const double den = 1 - std::pow((double)inv, (double)nlevels);
+  return (int)(nfeatures * ((double)num / den) * std::pow((double)inv, (double)l));
+}
+
+void make_tilemap(const OrbxPlan& plan, int tw, int th, bool use_pitch, OrbxTileMap* tm) {
+  int acc = 0;
+  for (int l = 0; l < plan.nlevels; l++) {
+    const int wcols = use_pitch ? plan.L[l].pitch : plan.L[l].w;
+    const int tx = (wcols + tw - 1) / tw, ty = (plan.L[l].h + th - 1) / th;
+    tm->begin[l] = acc;
+    tm->tiles_x[l] = tx;
+    acc += tx * ty;
+  }
+  for (int l = plan.nlevels; l <= ORBX_MAX_LEVELS; l++) tm->begin[l] = acc;
+}
+
+int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string* why) {
+  std::memset(plan, 0, sizeof(*plan));
+  plan->nlevels = p.nlevels;
+  plan->w0 = w0;
+  plan->h0 = h0;
+  size_t img_off = 0, mask_off = 0;
+  int cand_off = 0, out_cap = 0, xt = 0;
+  for (int l = 0; l < p.nlevels; l++) {
+    OrbxLevel& L = plan->L[l];
+    level_size(w0, h0, p.scale_factor, l, &L.w, &L.h);
+    if (L.w < 8 || L.h < 8) {
+      *why = "pyramid level " + std::to_string(l) + " is smaller than 8x8 (" + std::to_string(L.w) + "x" +
+             std::to_string(L.h) + ")";
+      return ORBX_ERR_UNSUPPORTED;
+    }
+    L.pitch = align_up(L.w, 64);
+    L.img_off = (int32_t)img_off;
+    img_off = align_up_sz(img_off + (size_t)L.pitch * L.h, 256);
+    L.mask_wpr = (L.w + 63) / 64;
+    L.mask_off = (int32_t)mask_off;
+    mask_off += (size_t)L.mask_wpr * L.h;
+    int quota;
+    if (p.select_mode == ORBX_SELECT_ROWMAJOR && p.nlevels == 1)
+      quota = p.nfeatures;  // OrientedFASTCPU::detect cap (src/orb_cpu.cpp:110)
+    else
+      quota = level_quota(p.nfeatures, p.scale_factor, p.nlevels, l);
+    if (quota < 0) quota = 0;
+    L.quota = quota;
+    L.cap = p.select_mode == ORBX_SELECT_HARRIS ? 2 * quota : quota;  // src/orb.cpp:63
+    if (p.select_mode == ORBX_SELECT_HARRIS && L.cap > ORBX_MAX_SELECT) {
+      *why = "per-level FAST cap " + std::to_string(L.cap) + " exceeds ORBX_MAX_SELECT";
+      return ORBX_ERR_UNSUPPORTED;
+    }
+    L.cand_off = cand_off;
+    cand_off += L.cap;
+    out_cap += quota;
+    L.scale = level_scale(p.scale_factor, l);
+    L.xtab_off = xt;
+    L.ytab_off = xt + (l == 0 ? 0 : L.w);
+    xt += (l == 0 ? 0 : L.w + L.h);
+    if (img_off > 0x7fffffffull) {
+      *why = "pyramid frame exceeds 2 GiB";
+      return ORBX_ERR_UNSUPPORTED;
+    }
+  }
+  plan->frame_bytes = (int32_t)img_off;
+  plan->mask_words = (int32_t)mask_off;
+  plan->cand_total = cand_off;
+  plan->out_cap = out_cap;
+  return ORBX_OK;
+}
+
+// 8-bit bilinear coefficient tables: OpenCV 4.x generic 8UC1 INTER_LINEAR path
+// (imgproc/src/resize.cpp: scale = 1/((double)dst/src); fx = (float)((dx+0.5)*
+// scale-0.5); sx = floor(fx); clamp with fx=0; 11-bit coefficients by cvRound).
+// OpenCV is not part of this image: PARITY UNPINNED (DESIGN.md "Pyramid").
+void make_taps(const OrbxPlan& plan, std::vector<OrbxResizeTap>* taps) {
+  size_t total = 0;
+  for (int l = 1; l < plan.nlevels; l++) total += (size_t)plan.L[l].w + plan.L[l].h;
+  taps->assign(total ? total : 1, OrbxResizeTap{0, 0, 0});
+  for (int l = 1; l < plan.nlevels; l++) {
+    const OrbxLevel& L = plan.L[l];
+    const double scale_x = 1. / ((double)L.w / plan.w0), scale_y = 1. / ((double)L.h / plan.h0);
+    for (int dx = 0; dx < L.w; dx++) {
+      float fx = (float)((dx + 0.5) * scale_x - 0.5);
+      int sx = (int)std::floor(fx);
+      fx -= (float)sx;
+      if (sx < 0) {
+        fx = 0;
+        sx = 0;
+      }
+      if (sx >= plan.w0 - 1) {
+        fx = 0;
+        sx = plan.w0 - 1;
+      }
+      OrbxResizeTap& t = (*taps)[L.xtab_off + dx];
+      t.ofs = sx;
+      t.c0 = (int16_t)std::lrintf((1.f - fx) * 2048.f);
+      t.c1 = (int16_t)std::lrintf(fx * 2048.f);
+    }
+    for (int dy = 0; dy < L.h; dy++) {
+      float fy = (float)((dy + 0.5) * scale_y - 0.5);
+      int sy = (int)std::floor(fy);
+      fy -= (float)sy;
+      OrbxResizeTap& t = (*taps)[L.ytab_off + dy];
+      t.ofs = sy;  // rows are clamped in the kernel, weights kept (OpenCV clips the row index only)
+      t.c0 = (int16_t)std::lrintf((1.f - fy) * 2048.f);
+      t.c1 = (int16_t)std::lrintf(fy * 2048.f);
+    }
+  }
+}
+
+// createGaussianKernel (src/GaussianBlur.cpp:7-37), host side like the reference
+int gaussian_kernel(int K, float sigma, float* kernel) {
+  if (K <= 0 || (K % 2) == 0 || !kernel) return ORBX_ERR_INVALID_ARG;
+  if (sigma <= 0.0f) sigma = 0.3f * ((K - 1) * 0.5f) + 0.8f;
+  const int half = K / 2;
+  float sum = 0.0f;
+  for (int y = -half; y <= half; ++y)
+    for (int x = -half; x <= half; ++x) {
+      const float value = std::exp(-(float)(x * x + y * y) / (2 * sigma * sigma));
+      kernel[(y + half) * K + (x + half)] = value;
+      sum += value;
+    }
+  for (int i = 0; i < K * K; ++i) kernel[i] /= sum;
+  return ORBX_OK;
+}
+
+int validate_params(const orbx_params& p, std::string* why) {
+  auto bad = [&](const char* m) {
+    *why = m;
+    return (int)ORBX_ERR_INVALID_ARG;
+  };
+  if (p.nfeatures < 0) return bad("nfeatures < 0");
+  if (!(p.scale_factor > 1.0f) || !(p.scale_factor <= 4.0f)) return bad("scale_factor must be in (1, 4]");
+  if (p.nlevels < 1 || p.nlevels > ORBX_MAX_LEVELS) return bad("nlevels must be in [1, 16]");
+  if (p.n < 1 || p.n > 16) return bad("n must be in [1, 16]");
+  if (p.threshold < 0 || p.threshold > 255) return bad("threshold must be in [0, 255]");
+  if (p.nms_window < 0 || p.nms_window / 2 > 3) return bad("nms_window must be in [0, 7]");
+  if (p.patch_size < 1 || p.patch_size / 2 > 20) return bad("patch_size must be in [1, 41]");
+  if (p.harris_window < 1 || (p.harris_window % 2) == 0 || p.harris_window > 15)
+    return bad("harris_window must be odd, in [1, 15]");
+  if (p.select_mode != ORBX_SELECT_HARRIS && p.select_mode != ORBX_SELECT_ROWMAJOR) return bad("select_mode");
+  if (p.blur_levels < 0 || p.blur_levels > 2) return bad("blur_levels");
+  if (p.blur_kind < 0 || p.blur_kind > 1) return bad("blur_kind");
+  if (p.max_width < 8 || p.max_height < 8 || p.max_width > 16384 || p.max_height > 16384)
+    return bad("max_width/max_height must be in [8, 16384]");
+  if (p.max_batch < 1 || p.max_batch > 65535) return bad("max_batch must be in [1, 65535]");
+  return ORBX_OK;
+}
+
+int set_plan(orbx_ctx* c, int w, int h) {
+  if (w == c->plan_w && h == c->plan_h) return ORBX_OK;
+  if (w < 8 || h < 8 || w > c->p.max_width || h > c->p.max_height)
+    return fail(c, ORBX_ERR_INVALID_ARG, "frame size outside [8, max_width] x [8, max_height]");
+  OrbxPlan plan;
+  std::string why;
+  int st = build_plan(c->p, w, h, &plan, &why);
+  if (st != ORBX_OK) return fail(c, st, why);
+  make_taps(plan, &c->h_taps);
+  if (c->h_taps.size() > c->taps_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "resize table exceeds pool");
+  // the table may still be in use by an in-flight batch of the previous size
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->d_taps, c->h_taps.data(), c->h_taps.size() * sizeof(OrbxResizeTap),
+                      hipMemcpyHostToDevice));
+  c->plan = plan;
+  make_tilemap(plan, ORBX_PYR_TW, ORBX_PYR_TH, true, &c->tm_pyr);
+  make_tilemap(plan, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &c->tm_blur);
+  make_tilemap(plan, ORBX_FAST_TW, ORBX_FAST_TH, false, &c->tm_fast);
+  c->plan_w = w;
+  c->plan_h = h;
+  return ORBX_OK;
+}
+
+bool blur_enabled(const orbx_ctx* c) { return c->p.blur_levels != ORBX_BLUR_NONE; }
+const uint8_t* final_pyr(const orbx_ctx* c) { return blur_enabled(c) ? c->d_pyr_blur : c->d_pyr; }
+
+// the whole path for n frames already on the device
+int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row_stride, size_t frame_stride,
+              hipStream_t s) {
+  int st = set_plan(c, w, h);
+  if (st != ORBX_OK) return st;
+  const OrbxPlan& P = c->plan;
+  const bool t = c->timing;
+  int e = 0;
+  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  HIPCHK(c, orbx_launch_pyramid(s, P, c->tm_pyr, n, d_frames, row_stride, frame_stride, c->d_taps, c->d_pyr));
+  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  if (blur_enabled(c))
+    HIPCHK(c, orbx_launch_blur(s, P, c->tm_blur, n, c->d_pyr, c->d_pyr_blur,
+                               c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
+  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2};
+  HIPCHK(c, orbx_launch_fast_nms(s, P, c->tm_fast, n, final_pyr(c), fp, c->d_mask, nullptr));
+  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  HIPCHK(c, orbx_launch_compact(s, P, n, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total));
+  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  if (c->p.select_mode == ORBX_SELECT_HARRIS)
+    HIPCHK(c, orbx_launch_harris(s, P, n, final_pyr(c), c->d_cand, c->d_cand_count, c->d_gauss,
+                                 c->p.harris_window, c->p.harris_k, c->d_resp));
+  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  // result block sections are laid out for (n, pool slot capacity)
+  c->out_layout = make_out_layout(n, P.out_cap > 0 ? P.out_cap : 1);
+  const OutLayout& o = c->out_layout;
+  HIPCHK(c, orbx_launch_select(s, P, n, c->p.select_mode, c->d_cand, c->d_cand_count, c->d_resp,
+                               (orbx_keypoint*)(c->d_out + o.lkp), (float*)(c->d_out + o.resp),
+                               (int32_t*)(c->d_out + o.level), (int32_t*)(c->d_out + o.counts)));
+  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  HIPCHK(c, orbx_launch_describe(s, P, n, final_pyr(c), c->p.patch_size, (const int32_t*)(c->d_out + o.counts),
+                                 (const orbx_keypoint*)(c->d_out + o.lkp), (const int32_t*)(c->d_out + o.level),
+                                 (orbx_keypoint*)(c->d_out + o.kp), (float*)(c->d_out + o.angle),
+                                 (orbx_descriptor*)(c->d_out + o.desc)));
+  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  c->last_n = n;
+  c->last_stream = s;
+  c->ev_valid = t;
+  return ORBX_OK;
+}
+
+int check_image(orbx_ctx* c, const void* img, int w, int h, int stride) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  if (!img) return fail(c, ORBX_ERR_INVALID_ARG, "image is NULL");
+  if (w < 8 || h < 8 || w > c->p.max_width || h > c->p.max_height)
+    return fail(c, ORBX_ERR_INVALID_ARG, "image size outside [8, max_width] x [8, max_height]");
+  if (stride < w) return fail(c, ORBX_ERR_INVALID_ARG, "stride < width");
+  return ORBX_OK;
+}
+
+// single-level plan over a scratch image, for the stage-level operators
+OrbxPlan flat_plan(int w, int h, int cap) {
+  OrbxPlan P;
+  std::memset(&P, 0, sizeof(P));
+  P.nlevels = 1;
+  P.w0 = w;
+  P.h0 = h;
+  OrbxLevel& L = P.L[0];
+  L.w = w;
+  L.h = h;
+  L.pitch = align_up(w, 64);
+  L.mask_wpr = (w + 63) / 64;
+  L.cap = cap;
+  L.quota = cap;
+  L.scale = 1.0f;
+  P.frame_bytes = (int32_t)align_up_sz((size_t)L.pitch * h, 256);
+  P.mask_words = L.mask_wpr * h;
+  P.cand_total = cap;
+  P.out_cap = cap;
+  return P;
+}
+
+// upload a host image into a zero-padded, 64-aligned-pitch scratch image
+int upload_flat(orbx_ctx* c, DevBuf& b, const uint8_t* img, int w, int h, int stride, int* pitch) {
+  const int p = align_up(w, 64);
+  int st = ensure(c, b, (size_t)p * h + 256);
+  if (st != ORBX_OK) return st;
+  HIPCHK(c, hipMemsetAsync(b.p, 0, (size_t)p * h, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(b.p, p, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
+  *pitch = p;
+  return ORBX_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+int orbx_params_default_gpu(orbx_params* p) {
+  if (!p) return ORBX_ERR_INVALID_ARG;
+  std::memset(p, 0, sizeof(*p));
+  p->nfeatures = 500;  // include/orb.hpp:36
+  p->scale_factor = 1.2f;
+  p->nlevels = 8;
+  p->threshold = 20;  // include/orb.hpp:12
+  p->n = 9;
+  p->nms_window = 3;
+  p->patch_size = 31;
+  p->harris_window = 7;  // src/orb.cpp:65
+  p->harris_k = 0.04f;
+  p->select_mode = ORBX_SELECT_HARRIS;
+  p->blur_levels = ORBX_BLUR_NONE;
+  p->blur_kind = ORBX_BLUR_SEP16;
+  p->max_width = 1920;
+  p->max_height = 1080;
+  p->max_batch = 1;
+  p->device = -1;
+  return ORBX_OK;
+}
+
+int orbx_params_default_cpu(orbx_params* p) {
+  int st = orbx_params_default_gpu(p);
+  if (st != ORBX_OK) return st;
+  p->nfeatures = 3000;  // include/orb_cpu.hpp:6
+  p->threshold = 50;
+  p->n = 9;
+  p->nms_window = 3;
+  p->patch_size = 9;
+  p->nlevels = 1;  // ORBCPU::detectAndCompute ignores the pyramid (src/orb_cpu.cpp:271-276)
+  p->select_mode = ORBX_SELECT_ROWMAJOR;
+  return ORBX_OK;
+}
+
+const char* orbx_status_string(int status) {
+  switch (status) {
+    case ORBX_OK:
+      return "ok";
+    case ORBX_ERR_INVALID_ARG:
+      return "invalid argument";
+    case ORBX_ERR_CAPACITY:
+      return "output capacity exceeded";
+    case ORBX_ERR_HIP:
+      return "HIP runtime error";
+    case ORBX_ERR_NO_DEVICE:
+      return "no usable gfx950 device";
+    case ORBX_ERR_UNSUPPORTED:
+      return "unsupported parameter combination";
+    default:
+      return "unknown status";
+  }
+}
+
+const char* orbx_version(void) { return "liborbx 0.1.0 gfx950"; }
+
+const char* orbx_last_error_string(const orbx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void orbx_destroy(orbx_ctx* c) {
+  if (!c) return;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  void* bufs[] = {c->d_in,   c->d_pyr,  c->d_pyr_blur, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total,
+                  c->d_resp, c->d_taps, c->d_gauss,    c->d_out};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (c->h_out) (void)hipHostFree(c->h_out);
+  DevBuf* sb[] = {&c->s_img_a, &c->s_img_b, &c->s_f32,  &c->s_u16, &c->s_mask,
+                  &c->s_kps,   &c->s_f32b,  &c->s_desc, &c->s_i32, &c->s_kern};
+  for (DevBuf* b : sb)
+    if (b->p) (void)hipFree(b->p);
+  for (auto& e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int orbx_create(const orbx_params* p, orbx_ctx** out) {
+  if (!p || !out) return fail(nullptr, ORBX_ERR_INVALID_ARG, "params/out is NULL");
+  *out = nullptr;
+  std::string why;
+  int st = validate_params(*p, &why);
+  if (st != ORBX_OK) return fail(nullptr, st, why);
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, ORBX_ERR_NO_DEVICE, "hipGetDeviceCount found no device (liborbx has no CPU fallback)");
+  int dev = p->device;
+  if (dev < 0) {
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  }
+  if (dev >= ndev) return fail(nullptr, ORBX_ERR_INVALID_ARG, "device ordinal out of range");
+  if (hipSetDevice(dev) != hipSuccess) return fail(nullptr, ORBX_ERR_NO_DEVICE, "hipSetDevice failed");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess)
+    return fail(nullptr, ORBX_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, ORBX_ERR_NO_DEVICE,
+                std::string("device is ") + prop.gcnArchName + ", liborbx is built for gfx950 only");
+
+  orbx_ctx* c = new (std::nothrow) orbx_ctx();
+  if (!c) return fail(nullptr, ORBX_ERR_HIP, "out of host memory");
+  c->p = *p;
+  c->device = dev;
+
+  st = build_plan(c->p, p->max_width, p->max_height, &c->plan_max, &why);
+  if (st != ORBX_OK) {
+    delete c;
+    return fail(nullptr, st, why);
+  }
+  const OrbxPlan& M = c->plan_max;
+  const size_t B = (size_t)p->max_batch;
+
+#define CREATE_CHK(expr)                                                                     \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      std::string m = std::string(#expr) + ": " + hipGetErrorString(_e);                     \
+      orbx_destroy(c);                                                                       \
+      return fail(nullptr, ORBX_ERR_HIP, m);                                                 \
+    }                                                                                        \
+  } while (0)
+
+  CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (auto& e : c->ev) CREATE_CHK(hipEventCreate(&e));
+  CREATE_CHK(hipMalloc((void**)&c->d_in, B * (size_t)p->max_width * p->max_height + 256));
+  CREATE_CHK(hipMalloc((void**)&c->d_pyr, B * (size_t)M.frame_bytes + 256));
+  if (p->blur_levels != ORBX_BLUR_NONE)
+    CREATE_CHK(hipMalloc((void**)&c->d_pyr_blur, B * (size_t)M.frame_bytes + 256));
+  CREATE_CHK(hipMalloc((void**)&c->d_mask, B * (size_t)M.mask_words * 8 + 256));
+  CREATE_CHK(hipMalloc((void**)&c->d_cand, B * (size_t)std::max(M.cand_total, 1) * sizeof(orbx_keypoint)));
+  CREATE_CHK(hipMalloc((void**)&c->d_cand_count, B * ORBX_MAX_LEVELS * sizeof(int32_t)));
+  CREATE_CHK(hipMalloc((void**)&c->d_cand_total, B * ORBX_MAX_LEVELS * sizeof(int32_t)));
+  CREATE_CHK(hipMalloc((void**)&c->d_resp, B * (size_t)std::max(M.cand_total, 1) * sizeof(float)));
+  {
+    size_t taps = 1;
+    for (int l = 1; l < M.nlevels; l++) taps += (size_t)M.L[l].w + M.L[l].h;
+    // level sizes of smaller frames never exceed those of the largest frame
+    c->taps_capacity = taps + 16;
+    CREATE_CHK(hipMalloc((void**)&c->d_taps, c->taps_capacity * sizeof(OrbxResizeTap)));
+  }
+  {
+    const int K = p->harris_window;
+    std::vector<float> g((size_t)K * K);
+    gaussian_kernel(K, -1.0f, g.data());
+    CREATE_CHK(hipMalloc((void**)&c->d_gauss, g.size() * sizeof(float)));
+    CREATE_CHK(hipMemcpy(c->d_gauss, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  c->out_cap = std::max(M.out_cap, 1);
+  {
+    const OutLayout o = make_out_layout((int)B, c->out_cap);
+    CREATE_CHK(hipMalloc((void**)&c->d_out, o.total));
+    CREATE_CHK(hipHostMalloc((void**)&c->h_out, o.total, hipHostMallocDefault));
+  }
+#undef CREATE_CHK
+  *out = c;
+  return ORBX_OK;
+}
+
+int orbx_get_plan(orbx_ctx* c, int width, int height, int32_t* level_w, int32_t* level_h, int32_t* quota,
+                  int32_t* fast_cap, float* level_scale_out, int32_t* out_capacity) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  OrbxPlan plan;
+  std::string why;
+  int st = build_plan(c->p, width, height, &plan, &why);
+  if (st != ORBX_OK) return fail(c, st, why);
+  for (int l = 0; l < plan.nlevels; l++) {
+    if (level_w) level_w[l] = plan.L[l].w;
+    if (level_h) level_h[l] = plan.L[l].h;
+    if (quota) quota[l] = plan.L[l].quota;
+    if (fast_cap) fast_cap[l] = plan.L[l].cap;
+    if (level_scale_out) level_scale_out[l] = plan.L[l].scale;
+  }
+  if (out_capacity) *out_capacity = plan.out_cap;
+  return ORBX_OK;
+}
+
+int orbx_detect_and_compute_batch_device(orbx_ctx* c, const void* d_frames, int n, int width, int height,
+                                         int row_stride, size_t frame_stride, void* stream) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  if (!d_frames) return fail(c, ORBX_ERR_INVALID_ARG, "d_frames is NULL");
+  if (n < 1 || n > c->p.max_batch) return fail(c, ORBX_ERR_INVALID_ARG, "n outside [1, max_batch]");
+  if (row_stride < width) return fail(c, ORBX_ERR_INVALID_ARG, "row_stride < width");
+  if (frame_stride < (size_t)row_stride * (size_t)(height - 1) + (size_t)width)
+    return fail(c, ORBX_ERR_INVALID_ARG, "frame_stride smaller than a frame");
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  return run_batch(c, (const uint8_t*)d_frames, n, width, height, row_stride, frame_stride, s);
+}
+
+int orbx_detect_and_compute_batch_host(orbx_ctx* c, const uint8_t* frames, int n, int width, int height,
+                                       int row_stride, size_t frame_stride) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  if (n < 1 || n > c->p.max_batch) return fail(c, ORBX_ERR_INVALID_ARG, "n outside [1, max_batch]");
+  int st = check_image(c, frames, width, height, row_stride);
+  if (st != ORBX_OK) return st;
+  if (n > 1 && frame_stride < (size_t)row_stride * (size_t)(height - 1) + (size_t)width)
+    return fail(c, ORBX_ERR_INVALID_ARG, "frame_stride smaller than a frame");
+  const size_t tight = (size_t)width * height;
+  if (row_stride == width && (n == 1 || frame_stride == tight)) {
+    HIPCHK(c, hipMemcpyAsync(c->d_in, frames, tight * n, hipMemcpyHostToDevice, c->stream));
+  } else {
+    for (int i = 0; i < n; i++)
+      HIPCHK(c, hipMemcpy2DAsync(c->d_in + tight * i, width, frames + frame_stride * i, row_stride, width, height,
+                                 hipMemcpyHostToDevice, c->stream));
+  }
+  return run_batch(c, c->d_in, n, width, height, width, tight, c->stream);
+}
+
+int orbx_wait(orbx_ctx* c) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->last_stream ? c->last_stream : c->stream));
+  if (c->ev_valid) {
+    for (int i = 0; i < ORBX_NUM_STAGE_TIMES - 1; i++)
+      HIPCHK(c, hipEventElapsedTime(&c->last_ms[i], c->ev[i], c->ev[i + 1]));
+    HIPCHK(c, hipEventElapsedTime(&c->last_ms[ORBX_NUM_STAGE_TIMES - 1], c->ev[0], c->ev[ORBX_NUM_STAGE_TIMES - 1]));
+    c->ev_valid = false;
+  }
+  return ORBX_OK;
+}
+
+int orbx_enable_stage_timing(orbx_ctx* c, int enable) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  c->timing = enable != 0;
+  return ORBX_OK;
+}
+
+int orbx_last_stage_times(orbx_ctx* c, float* ms) {
+  if (!c || !ms) return ORBX_ERR_INVALID_ARG;
+  std::memcpy(ms, c->last_ms, sizeof(c->last_ms));
+  return ORBX_OK;
+}
+
+int orbx_batch_results_device(orbx_ctx* c, orbx_batch_view* v) {
+  if (!c || !v) return ORBX_ERR_INVALID_ARG;
+  if (c->last_n <= 0) return fail(c, ORBX_ERR_INVALID_ARG, "no batch has been run");
+  const OutLayout& o = c->out_layout;
+  v->counts = (const int32_t*)(c->d_out + o.counts);
+  v->keypoints = (const orbx_keypoint*)(c->d_out + o.kp);
+  v->level_kps = (const orbx_keypoint*)(c->d_out + o.lkp);
+  v->orientations = (const float*)(c->d_out + o.angle);
+  v->responses = (const float*)(c->d_out + o.resp);
+  v->levels = (const int32_t*)(c->d_out + o.level);
+  v->descriptors = (const orbx_descriptor*)(c->d_out + o.desc);
+  v->slot_capacity = c->plan.out_cap > 0 ? c->plan.out_cap : 1;
+  v->n = c->last_n;
+  return ORBX_OK;
+}
+
+int orbx_batch_fetch(orbx_ctx* c, int first, int n, int32_t* counts, orbx_keypoint* keypoints,
+                     float* orientations, orbx_descriptor* descriptors, float* responses, int32_t* levels,
+                     orbx_keypoint* level_kps, int capacity) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  if (!counts) return fail(c, ORBX_ERR_INVALID_ARG, "counts is NULL");
+  if (first < 0 || n < 1 || first + n > c->last_n) return fail(c, ORBX_ERR_INVALID_ARG, "frame range outside batch");
+  if (capacity < 0) return fail(c, ORBX_ERR_INVALID_ARG, "capacity < 0");
+  const OutLayout& o = c->out_layout;
+  const int cap = c->plan.out_cap > 0 ? c->plan.out_cap : 1;
+  hipStream_t s = c->last_stream ? c->last_stream : c->stream;
+  // one D2H for the whole result block of the batch
+  HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, o.total, hipMemcpyDeviceToHost, s));
+  int st = orbx_wait(c);
+  if (st != ORBX_OK) return st;
+  const int32_t* hc = (const int32_t*)(c->h_out + o.counts);
+  bool truncated = false;
+  for (int i = 0; i < n; i++) {
+    const int f = first + i;
+    const int cnt = hc[f];
+    counts[i] = cnt;
+    const int m = std::min(cnt, capacity);
+    if (cnt > capacity) truncated = true;
+    const size_t so = (size_t)f * cap, dst = (size_t)i * capacity;
+    if (keypoints) std::memcpy(keypoints + dst, (const orbx_keypoint*)(c->h_out + o.kp) + so, sizeof(orbx_keypoint) * m);
+    if (level_kps) std::memcpy(level_kps + dst, (const orbx_keypoint*)(c->h_out + o.lkp) + so, sizeof(orbx_keypoint) * m);
+    if (orientations) std::memcpy(orientations + dst, (const float*)(c->h_out + o.angle) + so, sizeof(float) * m);
+    if (responses) std::memcpy(responses + dst, (const float*)(c->h_out + o.resp) + so, sizeof(float) * m);
+    if (levels) std::memcpy(levels + dst, (const int32_t*)(c->h_out + o.level) + so, sizeof(int32_t) * m);
+    if (descriptors)
+      std::memcpy(descriptors + dst, (const orbx_descriptor*)(c->h_out + o.desc) + so, sizeof(orbx_descriptor) * m);
+  }
+  if (truncated) return fail(c, ORBX_ERR_CAPACITY, "capacity smaller than keypoint count");
+  return ORBX_OK;
+}
+
+int orbx_detect_and_compute(orbx_ctx* c, const uint8_t* image, int width, int height, int stride,
+                            orbx_keypoint* keypoints, float* orientations, orbx_descriptor* descriptors,
+                            float* responses, int32_t* levels, orbx_keypoint* level_kps, int capacity,
+                            int* count) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  if (!count) return fail(c, ORBX_ERR_INVALID_ARG, "count is NULL");
+  int st = orbx_detect_and_compute_batch_host(c, image, 1, width, height, stride, (size_t)stride * height);
+  if (st != ORBX_OK) return st;
+  int32_t cnt = 0;
+  st = orbx_batch_fetch(c, 0, 1, &cnt, keypoints, orientations, descriptors, responses, levels, level_kps,
+                        capacity);
+  *count = cnt;
+  return st;
+}
+
+int orbx_bench_stage(orbx_ctx* c, int n_frames, int stage, int reps, float* avg_ms) {
+  if (!c || !avg_ms) return ORBX_ERR_INVALID_ARG;
+  if (c->plan_w == 0) return fail(c, ORBX_ERR_INVALID_ARG, "run a batch first (no pyramid built)");
+  if (n_frames < 1 || n_frames > c->last_n || reps < 1) return fail(c, ORBX_ERR_INVALID_ARG, "n_frames/reps");
+  const OrbxPlan& P = c->plan;
+  hipStream_t s = c->stream;
+  OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2};
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipEventRecord(c->ev[0], s));
+  for (int i = 0; i < reps; i++) {
+    switch (stage) {
+      case ORBX_STAGE_BLUR:
+        if (!blur_enabled(c)) return fail(c, ORBX_ERR_INVALID_ARG, "blur is disabled in this context");
+        HIPCHK(c, orbx_launch_blur(s, P, c->tm_blur, n_frames, c->d_pyr, c->d_pyr_blur,
+                                   c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
+        break;
+      case ORBX_STAGE_FAST:
+        HIPCHK(c, orbx_launch_fast_nms(s, P, c->tm_fast, n_frames, final_pyr(c), fp, c->d_mask, nullptr));
+        break;
+      case ORBX_STAGE_COMPACT:
+        HIPCHK(c, orbx_launch_compact(s, P, n_frames, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total));
+        break;
+      default:
+        return fail(c, ORBX_ERR_INVALID_ARG, "stage not benchmarkable in isolation");
+    }
+  }
+  HIPCHK(c, hipEventRecord(c->ev[1], s));
+  HIPCHK(c, hipEventSynchronize(c->ev[1]));
+  float ms = 0;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  *avg_ms = ms / reps;
+  return ORBX_OK;
+}
+
+// ---- stage-level operators --------------------------------------------------
+
+int orbx_fast_score(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, int threshold, int n,
+                    float* scores) {
+  int st = check_image(c, image, width, height, stride);
+  if (st != ORBX_OK) return st;
+  if (!scores || n < 1 || n > 16 || threshold < 0 || threshold > 255)
+    return fail(c, ORBX_ERR_INVALID_ARG, "scores NULL or n/threshold out of range");
+  int pitch;
+  st = upload_flat(c, c->s_img_a, image, width, height, stride, &pitch);
+  if (st != ORBX_OK) return st;
+  OrbxPlan P = flat_plan(width, height, 0);
+  OrbxTileMap tm;
+  make_tilemap(P, ORBX_FAST_TW, ORBX_FAST_TH, false, &tm);
+  const size_t npx = (size_t)width * height;
+  if ((st = ensure(c, c->s_u16, npx * 2)) != ORBX_OK) return st;
+  if ((st = ensure(c, c->s_mask, (size_t)P.mask_words * 8)) != ORBX_OK) return st;
+  OrbxFastParams fp{threshold, n, 0};
+  HIPCHK(c, orbx_launch_fast_nms(c->stream, P, tm, 1, (const uint8_t*)c->s_img_a.p, fp,
+                                 (unsigned long long*)c->s_mask.p, (uint16_t*)c->s_u16.p));
+  std::vector<uint16_t> h(npx);
+  HIPCHK(c, hipMemcpyAsync(h.data(), c->s_u16.p, npx * 2, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < npx; i++) scores[i] = (float)h[i];
+  return ORBX_OK;
+}
+
+static int compact_and_fetch(orbx_ctx* c, const OrbxPlan& P, int nfeatures, orbx_keypoint* keypoints, int* count,
+                             int* total) {
+  int st;
+  if ((st = ensure(c, c->s_kps, sizeof(orbx_keypoint) * (size_t)std::max(nfeatures, 1))) != ORBX_OK) return st;
+  if ((st = ensure(c, c->s_i32, 64)) != ORBX_OK) return st;
+  int32_t* d_cnt = (int32_t*)c->s_i32.p;
+  HIPCHK(c, orbx_launch_compact(c->stream, P, 1, (const unsigned long long*)c->s_mask.p, (orbx_keypoint*)c->s_kps.p,
+                                d_cnt, d_cnt + 1));
+  int32_t h[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (h[0] > 0)
+    HIPCHK(c, hipMemcpy(keypoints, c->s_kps.p, sizeof(orbx_keypoint) * (size_t)h[0], hipMemcpyDeviceToHost));
+  *count = h[0];
+  if (total) *total = h[1];
+  return ORBX_OK;
+}
+
+int orbx_fast(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, int threshold, int n,
+              int nms_window, int nfeatures, orbx_keypoint* keypoints, int* count, int* total) {
+  int st = check_image(c, image, width, height, stride);
+  if (st != ORBX_OK) return st;
+  if (!count || (!keypoints && nfeatures > 0) || nfeatures < 0 || n < 1 || n > 16 || threshold < 0 ||
+      threshold > 255 || nms_window < 0 || nms_window / 2 > 3)
+    return fail(c, ORBX_ERR_INVALID_ARG, "bad Fast() arguments");
+  int pitch;
+  st = upload_flat(c, c->s_img_a, image, width, height, stride, &pitch);
+  if (st != ORBX_OK) return st;
+  OrbxPlan P = flat_plan(width, height, nfeatures);
+  OrbxTileMap tm;
+  make_tilemap(P, ORBX_FAST_TW, ORBX_FAST_TH, false, &tm);
+  if ((st = ensure(c, c->s_mask, (size_t)P.mask_words * 8)) != ORBX_OK) return st;
+  OrbxFastParams fp{threshold, n, nms_window / 2};
+  HIPCHK(c, orbx_launch_fast_nms(c->stream, P, tm, 1, (const uint8_t*)c->s_img_a.p, fp,
+                                 (unsigned long long*)c->s_mask.p, nullptr));
+  return compact_and_fetch(c, P, nfeatures, keypoints, count, total);
+}
+
+int orbx_nms(orbx_ctx* c, const float* scores, int width, int height, int nms_window, int nfeatures,
+             float threshold, orbx_keypoint* keypoints, int* count, int* total) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  if (!scores || !count || (!keypoints && nfeatures > 0) || nfeatures < 0 || width < 1 || height < 1 ||
+      nms_window < 0 || nms_window / 2 > 3)
+    return fail(c, ORBX_ERR_INVALID_ARG, "bad NMS() arguments");
+  int st;
+  const size_t npx = (size_t)width * height;
+  if ((st = ensure(c, c->s_f32, npx * 4)) != ORBX_OK) return st;
+  OrbxPlan P = flat_plan(width, height, nfeatures);
+  if ((st = ensure(c, c->s_mask, (size_t)P.mask_words * 8)) != ORBX_OK) return st;
+  HIPCHK(c, hipMemcpyAsync(c->s_f32.p, scores, npx * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, orbx_launch_nms_f32(c->stream, (const float*)c->s_f32.p, width, height, nms_window / 2, threshold,
+                                (unsigned long long*)c->s_mask.p, P.L[0].mask_wpr));
+  return compact_and_fetch(c, P, nfeatures, keypoints, count, total);
+}
+
+static int describe_stage(orbx_ctx* c, const uint8_t* image, int width, int height, int stride,
+                          const orbx_keypoint* keypoints, int nkp, int patch_size, const float* angles_in,
+                          float* angles_out, orbx_descriptor* desc_out) {
+  int st = check_image(c, image, width, height, stride);
+  if (st != ORBX_OK) return st;
+  if (nkp < 0 || (nkp > 0 && !keypoints)) return fail(c, ORBX_ERR_INVALID_ARG, "keypoints NULL / nkp < 0");
+  if (patch_size < 1 || patch_size / 2 > 20) return fail(c, ORBX_ERR_INVALID_ARG, "patch_size must be in [1, 41]");
+  if (nkp == 0) return ORBX_OK;
+  for (int i = 0; i < nkp; i++)
+    if (keypoints[i].x < 0 || keypoints[i].y < 0 || keypoints[i].x >= width || keypoints[i].y >= height)
+      return fail(c, ORBX_ERR_INVALID_ARG, "keypoint outside the image");
+  if (angles_in)
+    for (int i = 0; i < nkp; i++)
+      if (!(std::fabs(angles_in[i]) < 100.0f))
+        return fail(c, ORBX_ERR_INVALID_ARG, "orientation must be finite and |angle| < 100 rad");
+  int pitch;
+  st = upload_flat(c, c->s_img_a, image, width, height, stride, &pitch);
+  if (st != ORBX_OK) return st;
+  if ((st = ensure(c, c->s_kps, sizeof(orbx_keypoint) * (size_t)nkp)) != ORBX_OK) return st;
+  if ((st = ensure(c, c->s_f32b, sizeof(float) * (size_t)nkp)) != ORBX_OK) return st;
+  if ((st = ensure(c, c->s_desc, sizeof(orbx_descriptor) * (size_t)nkp)) != ORBX_OK) return st;
+  HIPCHK(c, hipMemcpyAsync(c->s_kps.p, keypoints, sizeof(orbx_keypoint) * (size_t)nkp, hipMemcpyHostToDevice,
+                           c->stream));
+  if (angles_in)
+    HIPCHK(c, hipMemcpyAsync(c->s_f32b.p, angles_in, sizeof(float) * (size_t)nkp, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, orbx_launch_describe_flat(c->stream, (const uint8_t*)c->s_img_a.p, width, height, pitch,
+                                      (const orbx_keypoint*)c->s_kps.p, nkp, patch_size, angles_in != nullptr,
+                                      desc_out != nullptr, (float*)c->s_f32b.p, (orbx_descriptor*)c->s_desc.p));
+  if (angles_out)
+    HIPCHK(c, hipMemcpyAsync(angles_out, c->s_f32b.p, sizeof(float) * (size_t)nkp, hipMemcpyDeviceToHost, c->stream));
+  if (desc_out)
+    HIPCHK(c, hipMemcpyAsync(desc_out, c->s_desc.p, sizeof(orbx_descriptor) * (size_t)nkp, hipMemcpyDeviceToHost,
+                             c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ORBX_OK;
+}
+
+int orbx_orientations(orbx_ctx* c, const uint8_t* image, int width, int height, int stride,
+                      const orbx_keypoint* keypoints, int nkp, int patch_size, float* orientations) {
+  if (c && nkp > 0 && !orientations) return fail(c, ORBX_ERR_INVALID_ARG, "orientations is NULL");
+  return describe_stage(c, image, width, height, stride, keypoints, nkp, patch_size, nullptr, orientations, nullptr);
+}
+
+int orbx_brief(orbx_ctx* c, const uint8_t* image, int width, int height, int stride,
+               const orbx_keypoint* keypoints, const float* orientations, int nkp, orbx_descriptor* descriptors) {
+  if (c && nkp > 0 && (!orientations || !descriptors))
+    return fail(c, ORBX_ERR_INVALID_ARG, "orientations/descriptors is NULL");
+  return describe_stage(c, image, width, height, stride, keypoints, nkp, 31, orientations, nullptr, descriptors);
+}
+
+int orbx_harris(orbx_ctx* c, const uint8_t* image, int width, int height, int stride,
+                const orbx_keypoint* keypoints, int nkp, int window, float k, float* responses) {
+  int st = check_image(c, image, width, height, stride);
+  if (st != ORBX_OK) return st;
+  if (nkp < 0 || (nkp > 0 && (!keypoints || !responses)) || window < 1 || (window % 2) == 0 || window > 15)
+    return fail(c, ORBX_ERR_INVALID_ARG, "bad HarrisScore() arguments");
+  if (nkp == 0) return ORBX_OK;
+  for (int i = 0; i < nkp; i++)
+    if (keypoints[i].x < 0 || keypoints[i].y < 0 || keypoints[i].x >= width || keypoints[i].y >= height)
+      return fail(c, ORBX_ERR_INVALID_ARG, "keypoint outside the image");
+  int pitch;
+  st = upload_flat(c, c->s_img_a, image, width, height, stride, &pitch);
+  if (st != ORBX_OK) return st;
+  std::vector<float> g((size_t)window * window);
+  gaussian_kernel(window, -1.0f, g.data());
+  if ((st = ensure(c, c->s_kern, g.size() * 4)) != ORBX_OK) return st;
+  if ((st = ensure(c, c->s_kps, sizeof(orbx_keypoint) * (size_t)nkp)) != ORBX_OK) return st;
+  if ((st = ensure(c, c->s_f32b, sizeof(float) * (size_t)nkp)) != ORBX_OK) return st;
+  HIPCHK(c, hipMemcpyAsync(c->s_kern.p, g.data(), g.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->s_kps.p, keypoints, sizeof(orbx_keypoint) * (size_t)nkp, hipMemcpyHostToDevice,
+                           c->stream));
+  HIPCHK(c, orbx_launch_harris_flat(c->stream, (const uint8_t*)c->s_img_a.p, width, height, pitch,
+                                    (const orbx_keypoint*)c->s_kps.p, nkp, (const float*)c->s_kern.p, window, k,
+                                    (float*)c->s_f32b.p));
+  HIPCHK(c, hipMemcpyAsync(responses, c->s_f32b.p, sizeof(float) * (size_t)nkp, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ORBX_OK;
+}
+
+static int blur_stage(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, uint8_t* dst,
+                      int dst_stride, int kind) {
+  int st = check_image(c, image, width, height, stride);
+  if (st != ORBX_OK) return st;
+  if (!dst || dst_stride < width) return fail(c, ORBX_ERR_INVALID_ARG, "dst NULL or dst_stride < width");
+  int pitch;
+  st = upload_flat(c, c->s_img_a, image, width, height, stride, &pitch);
+  if (st != ORBX_OK) return st;
+  OrbxPlan P = flat_plan(width, height, 0);
+  if ((st = ensure(c, c->s_img_b, (size_t)P.frame_bytes + 256)) != ORBX_OK) return st;
+  OrbxTileMap tm;
+  make_tilemap(P, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &tm);
+  HIPCHK(c, orbx_launch_blur(c->stream, P, tm, 1, (const uint8_t*)c->s_img_a.p, (uint8_t*)c->s_img_b.p, 0, kind));
+  HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, c->s_img_b.p, pitch, width, height, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ORBX_OK;
+}
+
+int orbx_blur5_sep(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, uint8_t* dst,
+                   int dst_stride) {
+  return blur_stage(c, image, width, height, stride, dst, dst_stride, ORBX_BLUR_SEP16);
+}
+
+int orbx_blur5_273(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, uint8_t* dst,
+                   int dst_stride) {
+  return blur_stage(c, image, width, height, stride, dst, dst_stride, ORBX_BLUR_K273);
+}
+
+static int conv_stage(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, const float* kernel,
+                      int K, int reflect_pad, uint8_t* dst) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  if (!image || !kernel || !dst || width < 1 || height < 1 || stride < width || K < 1 || (K % 2) == 0 || K > 31)
+    return fail(c, ORBX_ERR_INVALID_ARG, "bad conv2d() arguments (kernel_size must be odd, <= 31)");
+  const int wo = reflect_pad ? width : width - K + 1, ho = reflect_pad ? height : height - K + 1;
+  if (wo < 1 || ho < 1) return fail(c, ORBX_ERR_INVALID_ARG, "image smaller than the kernel");
+  if (reflect_pad && (width < K / 2 + 1 || height < K / 2 + 1))
+    return fail(c, ORBX_ERR_INVALID_ARG, "image too small for REFLECT_101 padding");
+  int st, pitch;
+  const int p = align_up(width, 64);
+  if ((st = ensure(c, c->s_img_a, (size_t)p * height + 256)) != ORBX_OK) return st;
+  HIPCHK(c, hipMemcpy2DAsync(c->s_img_a.p, p, image, stride, width, height, hipMemcpyHostToDevice, c->stream));
+  pitch = p;
+  if ((st = ensure(c, c->s_img_b, (size_t)wo * ho + 256)) != ORBX_OK) return st;
+  if ((st = ensure(c, c->s_kern, (size_t)K * K * 4)) != ORBX_OK) return st;
+  HIPCHK(c, hipMemcpyAsync(c->s_kern.p, kernel, (size_t)K * K * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, orbx_launch_conv2d(c->stream, (const uint8_t*)c->s_img_a.p, width, height, pitch,
+                               (const float*)c->s_kern.p, K, reflect_pad, (uint8_t*)c->s_img_b.p, wo));
+  HIPCHK(c, hipMemcpyAsync(dst, c->s_img_b.p, (size_t)wo * ho, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ORBX_OK;
+}
+
+int orbx_conv2d(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, const float* kernel,
+                int kernel_size, uint8_t* dst) {
+  return conv_stage(c, image, width, height, stride, kernel, kernel_size, 0, dst);
+}
+
+int orbx_gaussian_kernel(int kernel_size, float sigma, float* kernel) {
+  return gaussian_kernel(kernel_size, sigma, kernel);
+}
+
+int orbx_gaussian_blur_conv(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, int kernel_size,
+                            uint8_t* dst) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  if (kernel_size < 1 || (kernel_size % 2) == 0 || kernel_size > 31)
+    return fail(c, ORBX_ERR_INVALID_ARG, "kernel_size must be odd and <= 31 (src/GaussianBlur.cpp:8-11)");
+  std::vector<float> g((size_t)kernel_size * kernel_size);
+  gaussian_kernel(kernel_size, -1.0f, g.data());
+  return conv_stage(c, image, width, height, stride, g.data(), kernel_size, 1, dst);
+}
+
+int orbx_sobel(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, int dir, uint8_t* dst) {
+  static const float SX[9] = {-1.f, 0.f, 1.f, -2.f, 0.f, 2.f, -1.f, 0.f, 1.f};   // src/Sobel.cpp:6-10
+  static const float SY[9] = {-1.f, -2.f, -1.f, 0.f, 0.f, 0.f, 1.f, 2.f, 1.f};   // src/Sobel.cpp:12-16
+  return conv_stage(c, image, width, height, stride, dir == 0 ? SX : SY, 3, 1, dst);
+}
+
+int orbx_build_pyramid_level(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, int level,
+                             uint8_t* dst, int* level_w, int* level_h) {
+  int st = check_image(c, image, width, height, stride);
+  if (st != ORBX_OK) return st;
+  if (level < 0 || level >= c->p.nlevels || !dst) return fail(c, ORBX_ERR_INVALID_ARG, "level out of range / dst NULL");
+  if ((st = set_plan(c, width, height)) != ORBX_OK) return st;
+  const OrbxPlan& P = c->plan;
+  HIPCHK(c, hipMemcpy2DAsync(c->d_in, width, image, stride, width, height, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, orbx_launch_pyramid(c->stream, P, c->tm_pyr, 1, c->d_in, width, (size_t)width * height, c->d_taps,
+                                c->d_pyr));
+  if (blur_enabled(c))
+    HIPCHK(c, orbx_launch_blur(c->stream, P, c->tm_blur, 1, c->d_pyr, c->d_pyr_blur,
+                               c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
+  const OrbxLevel& L = P.L[level];
+  HIPCHK(c, hipMemcpy2DAsync(dst, L.w, final_pyr(c) + L.img_off, L.pitch, L.w, L.h, hipMemcpyDeviceToHost,
+                             c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (level_w) *level_w = L.w;
+  if (level_h) *level_h = L.h;
+  return ORBX_OK;
+}
+
+int orbx_select_top(orbx_ctx* c, const float* responses, int n, int keep, int32_t* indices, int* kept) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  if (n < 0 || keep < 0 || (n > 0 && (!responses || !indices)) || !kept)
+    return fail(c, ORBX_ERR_INVALID_ARG, "bad select_top arguments");
+  const int m = std::min(n, keep);
+  *kept = m;
+  if (m == 0) return ORBX_OK;
+  int st;
+  if ((st = ensure(c, c->s_f32b, sizeof(float) * (size_t)n)) != ORBX_OK) return st;
+  if ((st = ensure(c, c->s_i32, sizeof(int32_t) * (size_t)n)) != ORBX_OK) return st;
+  HIPCHK(c, hipMemcpyAsync(c->s_f32b.p, responses, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, orbx_launch_select_flat(c->stream, (const float*)c->s_f32b.p, n, keep, (int32_t*)c->s_i32.p));
+  HIPCHK(c, hipMemcpyAsync(indices, c->s_i32.p, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ORBX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// orbx_internal.h -- shared between the HIP kernels (orbx_kernels.hip) and the
+// C-ABI host layer (orbx_api.cpp).  Not part of the public interface.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orbx.h"
+
+// ---- HBM layout ------------------------------------------------------------
+// A "pyramid frame" holds all levels of one input frame back to back:
+//   level l at byte offset img_off, `h` rows of `pitch` bytes, pitch = W_l
+//   rounded up to 64 (so every tile row starts 4-byte aligned and a 64-pixel
+//   tile row never straddles the allocation), level offsets 256-B aligned.
+// The NMS survivor mask of a level is h rows of `mask_wpr` 64-bit words
+// (bit x&63 of word x>>6), all levels back to back at mask_off (in words).
+// Candidate keypoints / Harris responses of a frame live in `cand_total`
+// slots, level l owning [cand_off, cand_off + cap).
+struct OrbxLevel {
+  int32_t w, h, pitch;
+  int32_t img_off;   // bytes, within a pyramid frame
+  int32_t mask_wpr;  // u64 words per mask row
+  int32_t mask_off;  // u64 words, within a frame's mask block
+  int32_t cap;       // FAST cap (row-major)        src/orb.cpp:63
+  int32_t quota;     // kept after selection        src/orb.cpp:62
+  int32_t cand_off;  // first candidate slot
+  int32_t xtab_off;  // first entry of this level's resize x-table
+  int32_t ytab_off;  // first entry of this level's resize y-table
+  float scale;       // (float)pow(scaleFactor, l)  src/orb.cpp:95
+};
+
+struct OrbxPlan {
+  int32_t nlevels;
+  int32_t w0, h0;
+  int32_t frame_bytes;  // pyramid frame stride (bytes)
+  int32_t mask_words;   // mask stride per frame (u64 words)
+  int32_t cand_total;   // candidate slots per frame
+  int32_t out_cap;      // result slots per frame (sum of quotas)
+  OrbxLevel L[ORBX_MAX_LEVELS];
+};
+
+// blockIdx.x -> (level, tile) map for one kernel's tile size
+struct OrbxTileMap {
+  int32_t begin[ORBX_MAX_LEVELS + 1];  // first tile id of each level (+ total)
+  int32_t tiles_x[ORBX_MAX_LEVELS];
+};
+
+// 8-bit bilinear resize coefficient (OpenCV-style 11-bit fixed point)
+struct OrbxResizeTap {
+  int32_t ofs;     // source index (clamped)
+  int16_t c0, c1;  // weights of src[ofs], src[ofs+1]; c0+c1 ~ 2048
+};
+
+struct OrbxFastParams {
+  int32_t threshold, n, nms_radius;
+};
+
+// tile geometry of the FAST/NMS kernel
+#define ORBX_FAST_TW 64
+#define ORBX_FAST_TH 32
+// tile geometry of the blur kernel
+#define ORBX_BLUR_TW 64
+#define ORBX_BLUR_TH 16
+// tile geometry of the pyramid kernel (each thread: 4 px)
+#define ORBX_PYR_TW 256
+#define ORBX_PYR_TH 4
+
+#define ORBX_MAX_SELECT 8192  // largest per-level FAST cap the select kernel ranks in LDS
+
+// ---- launchers (orbx_kernels.hip) ------------------------------------------
+// All take the stream explicitly and never synchronise or allocate.
+hipError_t orbx_launch_pyramid(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
+                               const uint8_t* d_in, int in_stride, size_t in_frame_stride,
+                               const OrbxResizeTap* d_taps, uint8_t* d_pyr);
+hipError_t orbx_launch_blur(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
+                            const uint8_t* d_src, uint8_t* d_dst, int first_level, int kind);
+hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
+                                const uint8_t* d_pyr, OrbxFastParams fp, unsigned long long* d_mask,
+                                uint16_t* d_scores_dbg);
+hipError_t orbx_launch_compact(hipStream_t s, const OrbxPlan& plan, int n_frames,
+                               const unsigned long long* d_mask, orbx_keypoint* d_cand, int32_t* d_cand_count,
+                               int32_t* d_cand_total);
+hipError_t orbx_launch_harris(hipStream_t s, const OrbxPlan& plan, int n_frames, const uint8_t* d_pyr,
+                              const orbx_keypoint* d_cand, const int32_t* d_cand_count, const float* d_gauss,
+                              int window, float k, float* d_resp);
+hipError_t orbx_launch_select(hipStream_t s, const OrbxPlan& plan, int n_frames, int mode,
+                              const orbx_keypoint* d_cand, const int32_t* d_cand_count, const float* d_resp,
+                              orbx_keypoint* d_out_lkp, float* d_out_resp, int32_t* d_out_level,
+                              int32_t* d_out_count);
+hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frames, const uint8_t* d_pyr,
+                                int patch_size, const int32_t* d_out_count, const orbx_keypoint* d_out_lkp,
+                                const int32_t* d_out_level, orbx_keypoint* d_out_kp, float* d_out_angle,
+                                orbx_descriptor* d_out_desc);
+
+// stage-level helpers on plain (single-image, arbitrary pitch) buffers
+hipError_t orbx_launch_describe_flat(hipStream_t s, const uint8_t* d_img, int w, int h, int pitch,
+                                     const orbx_keypoint* d_kps, int nkp, int patch_size, int use_given_angles,
+                                     int do_brief, float* d_angles, orbx_descriptor* d_desc);
+hipError_t orbx_launch_nms_f32(hipStream_t s, const float* d_scores, int w, int h, int radius, float threshold,
+                               unsigned long long* d_mask, int mask_wpr);
+hipError_t orbx_launch_conv2d(hipStream_t s, const uint8_t* d_img, int w, int h, int pitch, const float* d_kernel,
+                              int K, int reflect_pad, uint8_t* d_dst, int dst_pitch);
+hipError_t orbx_launch_select_flat(hipStream_t s, const float* d_resp, int n, int keep, int32_t* d_idx);

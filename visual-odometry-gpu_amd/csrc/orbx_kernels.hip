@@ -1,0 +1,878 @@
+// orbx_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the ORB front-end.
+//
+// Design notes (see DESIGN.md for the full picture):
+//  * 64-lane wavefronts everywhere: 256-thread workgroups = 4 waves; wave
+//    ballots (64-bit) do the FAST candidate compaction, the NMS survivor
+//    bit-mask (one 64-pixel tile row == one ballot == one u64 store) and the
+//    BRIEF bit packing (4 ballots == one 256-bit descriptor).
+//  * Every image read is a row-coalesced, 4-byte-aligned dword load into an
+//    LDS tile that includes the halo; all 8-bit stencil work then runs out of
+//    LDS.  No MFMA: this path is integer stencil / gather, HBM-bound.
+//  * All levels of all frames of a batch are covered by ONE launch per stage
+//    (blockIdx.x -> (level, tile) through OrbxTileMap, blockIdx.y -> frame).
+//  * Keypoint order is deterministic (row-major), never atomics-ordered.
+//  * Integer arithmetic wherever the reference's float arithmetic is exact, so
+//    results are bit-identical to the CPU oracle; the float parts (angles,
+//    rotation, Harris) use orbx_math.h and -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "orbx_internal.h"
+#include "orbx_math.h"
+
+typedef unsigned long long u64;
+
+__constant__ int8_t c_pattern[1024] = {
+#include "pattern_31.inc"
+};
+
+// ---------------------------------------------------------------------------
+// helpers
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// (level, tile_x, tile_y) of this workgroup
+__device__ __forceinline__ void decode_tile(const OrbxTileMap& tm, int nlevels, int& l, int& tx, int& ty) {
+  const int t = blockIdx.x;
+  l = 0;
+#pragma unroll 1
+  for (int i = 1; i < nlevels; i++)
+    if (t >= tm.begin[i]) l = i;
+  const int local = t - tm.begin[l];
+  ty = local / tm.tiles_x[l];
+  tx = local - ty * tm.tiles_x[l];
+}
+
+// BORDER_REFLECT_101 for p in [-len+1, 2*len-2], clamped otherwise
+// (src/cuda/GaussianBlur1D.cu:27-32)
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (p < 0) p = -p;
+  if (p >= len) p = 2 * len - p - 2;
+  p = p < 0 ? 0 : p;
+  return p >= len ? len - 1 : p;
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// 1. pyramid: level 0 copy + fixed-point bilinear resize of every level >= 1
+//    straight from level 0 (src/orb.cpp:111-120).  Each thread produces 4
+//    horizontally adjacent pixels and stores one dword.
+__global__ __launch_bounds__(256) void k_pyramid(OrbxPlan plan, OrbxTileMap tm, const uint8_t* __restrict__ in,
+                                                 int in_stride, size_t in_frame_stride,
+                                                 const OrbxResizeTap* __restrict__ taps,
+                                                 uint8_t* __restrict__ pyr) {
+  int l, tx, ty;
+  decode_tile(tm, plan.nlevels, l, tx, ty);
+  const OrbxLevel& L = plan.L[l];
+  const int f = blockIdx.y;
+  const uint8_t* src = in + (size_t)f * in_frame_stride;
+  uint8_t* dst = pyr + (size_t)f * plan.frame_bytes + L.img_off;
+  const int x = tx * ORBX_PYR_TW + (threadIdx.x & 63) * 4;
+  const int y = ty * ORBX_PYR_TH + (threadIdx.x >> 6);
+  if (y >= L.h || x >= L.pitch) return;
+  uint32_t out = 0;
+  if (l == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int xx = x + k;
+      const uint32_t v = xx < L.w ? src[(size_t)y * in_stride + xx] : 0u;
+      out |= v << (8 * k);
+    }
+  } else {
+    const OrbxResizeTap ty_ = taps[L.ytab_off + y];
+    int sy0 = ty_.ofs, sy1 = ty_.ofs + 1;
+    sy0 = min(max(sy0, 0), plan.h0 - 1);
+    sy1 = min(max(sy1, 0), plan.h0 - 1);
+    const uint8_t* S0 = src + (size_t)sy0 * in_stride;
+    const uint8_t* S1 = src + (size_t)sy1 * in_stride;
+    const int b0 = ty_.c0, b1 = ty_.c1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int xx = x + k;
+      if (xx < L.w) {
+        const OrbxResizeTap t = taps[L.xtab_off + xx];
+        const int sx = t.ofs, sx1 = min(sx + 1, plan.w0 - 1);
+        const int r0 = S0[sx] * t.c0 + S0[sx1] * t.c1;
+        const int r1 = S1[sx] * t.c0 + S1[sx1] * t.c1;
+        const uint32_t v = (uint32_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+        out |= v << (8 * k);
+      }
+    }
+  }
+  *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.pitch + x) = out;
+}
+
+// ---------------------------------------------------------------------------
+// 2. 5x5 Gaussian blur, REFLECT_101.
+//    kind 0: separable [1 4 6 4 1]/16 twice then round-half-even
+//            == rne(sum_ij w_i w_j p / 256)   (src/cuda/GaussianBlur1D.cu:34-163;
+//            every float intermediate there is an exact dyadic, so integer
+//            arithmetic reproduces it bit for bit)
+//    kind 1: 5x5 /273 kernel, rne(S/273)      (src/cuda/GaussianBlur.cu:21-130;
+//            S/273 is never within float error of a .5 tie because 273 is odd)
+//    Levels below first_level are copied unchanged.
+#define BLUR_SROWS (ORBX_BLUR_TH + 4)
+#define BLUR_SPITCH 72  // bytes: x0-4 .. x0+67
+
+__device__ __forceinline__ void blur_load_tile(uint8_t* s_src, const uint8_t* img, const OrbxLevel& L, int x0,
+                                               int y0) {
+  uint32_t* s32 = reinterpret_cast<uint32_t*>(s_src);
+  for (int i = threadIdx.x; i < BLUR_SROWS * (BLUR_SPITCH / 4); i += 256) {
+    const int row = i / (BLUR_SPITCH / 4), c = i - row * (BLUR_SPITCH / 4);
+    const int gy = reflect101(y0 - 2 + row, L.h);
+    const int gx = x0 - 4 + 4 * c;
+    uint32_t v = 0;
+    if (gx >= 0 && gx + 4 <= L.pitch) v = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * L.pitch + gx);
+    s32[i] = v;
+  }
+  __syncthreads();
+  // horizontal REFLECT_101 fix-up of the two halo columns on image borders
+  if (threadIdx.x < BLUR_SROWS) {
+    uint8_t* row = s_src + threadIdx.x * BLUR_SPITCH;
+    if (x0 == 0) {
+      row[3] = row[5];  // x=-1 <- x=1
+      row[2] = row[6];  // x=-2 <- x=2
+    }
+    const int rem = L.w - x0;  // valid columns in this tile
+    if (rem <= ORBX_BLUR_TW + 1) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int x = L.w + k;  // needs reflect
+        const int col = x - x0 + 4;
+        if (col < BLUR_SPITCH) row[col] = row[(2 * L.w - x - 2) - x0 + 4];
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_blur(OrbxPlan plan, OrbxTileMap tm, const uint8_t* __restrict__ src,
+                                              uint8_t* __restrict__ dst, int first_level, int kind) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_src[BLUR_SROWS * BLUR_SPITCH];
+  __shared__ __attribute__((aligned(16))) uint16_t s_h[BLUR_SROWS * ORBX_BLUR_TW];
+  int l, tx, ty;
+  decode_tile(tm, plan.nlevels, l, tx, ty);
+  const OrbxLevel& L = plan.L[l];
+  const int f = blockIdx.y;
+  const uint8_t* img = src + (size_t)f * plan.frame_bytes + L.img_off;
+  uint8_t* out = dst + (size_t)f * plan.frame_bytes + L.img_off;
+  const int x0 = tx * ORBX_BLUR_TW, y0 = ty * ORBX_BLUR_TH;
+  const int c4 = (threadIdx.x & 15) * 4, r = threadIdx.x >> 4;
+  const int gy = y0 + r, gx = x0 + c4;
+
+  if (l < first_level) {  // pass-through copy
+    if (gy < L.h && gx < L.pitch)
+      *reinterpret_cast<uint32_t*>(out + (size_t)gy * L.pitch + gx) =
+          *reinterpret_cast<const uint32_t*>(img + (size_t)gy * L.pitch + gx);
+    return;
+  }
+  blur_load_tile(s_src, img, L, x0, y0);
+
+  uint32_t packed = 0;
+  if (kind == 0) {
+    // horizontal pass -> u16 (<= 4080)
+    for (int i = threadIdx.x; i < BLUR_SROWS * ORBX_BLUR_TW; i += 256) {
+      const int row = i >> 6, c = i & 63;
+      const uint8_t* p = s_src + row * BLUR_SPITCH + c + 2;  // p[0] is x-2
+      s_h[i] = (uint16_t)(p[0] + 4 * p[1] + 6 * p[2] + 4 * p[3] + p[4]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint16_t* h = s_h + r * ORBX_BLUR_TW + c4 + k;  // h[0] is y-2
+      const uint32_t S = h[0] + 4u * h[ORBX_BLUR_TW] + 6u * h[2 * ORBX_BLUR_TW] + 4u * h[3 * ORBX_BLUR_TW] +
+                         h[4 * ORBX_BLUR_TW];
+      const uint32_t v = (S + 127u + ((S >> 8) & 1u)) >> 8;  // round-half-even of S/256
+      if (gx + k < L.w) packed |= v << (8 * k);
+    }
+  } else {
+    const int kw[25] = {1, 4, 7, 4, 1, 4, 16, 26, 16, 4, 7, 26, 41, 26, 7, 4, 16, 26, 16, 4, 1, 4, 7, 4, 1};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t S = 0;
+#pragma unroll
+      for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j < 5; j++) S += (uint32_t)kw[i * 5 + j] * s_src[(r + i) * BLUR_SPITCH + c4 + k + 2 + j];
+      const uint32_t v = (2u * S + 273u) / 546u;  // nearest integer to S/273 (no ties exist)
+      if (gx + k < L.w) packed |= v << (8 * k);
+    }
+  }
+  if (gy < L.h && gx < L.pitch) *reinterpret_cast<uint32_t*>(out + (size_t)gy * L.pitch + gx) = packed;
+}
+
+// ---------------------------------------------------------------------------
+// 3. FAST-n segment test + score + (2r+1)^2 NMS, fused, one 64x32 tile per
+//    workgroup (src/orb_cpu.cpp:23-134; src/cuda/Fast.cu:30-209,
+//    src/cuda/NMS.cu:21-128).
+//    phase 1  row-coalesced dword loads of tile+halo into LDS
+//    phase 2  4-point pre-test on every pixel of the score region; survivors
+//             are compacted into an LDS queue with a wave ballot + popcount
+//    phase 3  dense full segment test + score on the queue (no divergence)
+//    phase 4  NMS out of the LDS score tile; one ballot per 64-pixel row
+//             becomes one u64 of the survivor mask
+#define FAST_IMG_PITCH 80                    // bytes: x0-8 .. x0+71
+#define FAST_IMG_ROWS (ORBX_FAST_TH + 12)    // r <= 3
+#define FAST_SC_PITCH 72                     // u16 entries: 64 + 2*3 rounded up
+#define FAST_SC_ROWS (ORBX_FAST_TH + 6)
+
+__device__ __forceinline__ bool has_run16(uint32_t m, int n) {
+  uint32_t x = m | (m << 16);
+  uint32_t acc = x;
+  int k = 1;
+  while (2 * k <= n) {
+    acc &= acc >> k;
+    k *= 2;
+  }
+  if (k < n) acc &= acc >> (n - k);
+  return (acc & 0xffffu) != 0;
+}
+
+template <bool WRITE_SCORES>
+__global__ __launch_bounds__(256) void k_fast_nms(OrbxPlan plan, OrbxTileMap tm, const uint8_t* __restrict__ pyr,
+                                                  OrbxFastParams fp, u64* __restrict__ mask,
+                                                  uint16_t* __restrict__ scores_dbg) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_img32[FAST_IMG_ROWS * (FAST_IMG_PITCH / 4)];
+  __shared__ __attribute__((aligned(16))) uint16_t s_score[FAST_SC_ROWS * FAST_SC_PITCH];
+  __shared__ uint16_t s_queue[FAST_SC_ROWS * (ORBX_FAST_TW + 6)];
+  __shared__ int s_qn;
+
+  int l, tx, ty;
+  decode_tile(tm, plan.nlevels, l, tx, ty);
+  const OrbxLevel& L = plan.L[l];
+  const int f = blockIdx.y;
+  const uint8_t* img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int r = fp.nms_radius, thr = fp.threshold;
+  const int x0 = tx * ORBX_FAST_TW, y0 = ty * ORBX_FAST_TH;
+  const int gy0 = y0 - 3 - r;
+  const int nrows = ORBX_FAST_TH + 6 + 2 * r;
+
+  // phase 1
+  for (int i = tid; i < nrows * (FAST_IMG_PITCH / 4); i += 256) {
+    const int row = i / (FAST_IMG_PITCH / 4), c = i - row * (FAST_IMG_PITCH / 4);
+    const int gy = gy0 + row, gx = x0 - 8 + 4 * c;
+    uint32_t v = 0;
+    if (gy >= 0 && gy < L.h && gx >= 0 && gx + 4 <= L.pitch)
+      v = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * L.pitch + gx);
+    s_img32[i] = v;
+  }
+  for (int i = tid; i < FAST_SC_ROWS * FAST_SC_PITCH / 2; i += 256) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
+  if (tid == 0) s_qn = 0;
+  __syncthreads();
+
+  // phase 2: pre-test (src/orb_cpu.cpp:39-58)
+  const uint8_t* s_img = reinterpret_cast<const uint8_t*>(s_img32);
+  const int SW = ORBX_FAST_TW + 2 * r, SH = ORBX_FAST_TH + 2 * r, N = SW * SH;
+  for (int base = 0; base < N; base += 256) {
+    const int i = base + tid;
+    bool cand = false;
+    if (i < N) {
+      const int sy = i / SW, sx = i - sy * SW;
+      const int gx = x0 - r + sx, gy = y0 - r + sy;
+      if (gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3) {
+        const uint8_t* p = s_img + (sy + 3) * FAST_IMG_PITCH + (sx - r + 8);
+        const int Ip = p[0], hi = Ip + thr, lo = Ip - thr;
+        const int a = p[-3 * FAST_IMG_PITCH], b = p[3], c = p[3 * FAST_IMG_PITCH], d = p[-3];
+        const int ba = a >= hi, bb = b >= hi, bc = c >= hi, bd = d >= hi;
+        const int br = ba + bb + bc + bd;
+        const int dk = (!ba && a <= lo) + (!bb && b <= lo) + (!bc && c <= lo) + (!bd && d <= lo);
+        cand = max(br, dk) >= 3;
+      }
+    }
+    const u64 m = __ballot(cand);
+    if (m) {
+      int wbase = 0;
+      if (lane == 0) wbase = atomicAdd(&s_qn, __popcll(m));
+      wbase = __shfl(wbase, 0, 64);
+      if (cand) s_queue[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+    }
+  }
+  __syncthreads();
+
+  // phase 3: full segment test + score on compacted candidates (src/orb_cpu.cpp:61-101)
+  const int nq = s_qn;
+  for (int q = tid; q < nq; q += 256) {
+    const int i = s_queue[q];
+    const int sy = i / SW, sx = i - sy * SW;
+    const uint8_t* p = s_img + (sy + 3) * FAST_IMG_PITCH + (sx - r + 8);
+    const int Ip = p[0], hi = Ip + thr, lo = Ip - thr;
+    const int ring[16] = {p[-3 * FAST_IMG_PITCH],     p[-3 * FAST_IMG_PITCH + 1], p[-2 * FAST_IMG_PITCH + 2],
+                          p[-1 * FAST_IMG_PITCH + 3], p[3],                       p[FAST_IMG_PITCH + 3],
+                          p[2 * FAST_IMG_PITCH + 2],  p[3 * FAST_IMG_PITCH + 1],  p[3 * FAST_IMG_PITCH],
+                          p[3 * FAST_IMG_PITCH - 1],  p[2 * FAST_IMG_PITCH - 2],  p[FAST_IMG_PITCH - 3],
+                          p[-3],                      p[-FAST_IMG_PITCH - 3],     p[-2 * FAST_IMG_PITCH - 2],
+                          p[-3 * FAST_IMG_PITCH - 1]};
+    uint32_t bm = 0, dm = 0;
+    int score = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int v = ring[k];
+      bm |= (uint32_t)(v >= hi) << k;
+      dm |= (uint32_t)(v <= lo) << k;
+      score += abs(Ip - v);
+    }
+    if (has_run16(bm, fp.n) || has_run16(dm, fp.n)) s_score[sy * FAST_SC_PITCH + sx] = (uint16_t)score;
+  }
+  __syncthreads();
+
+  // phase 4: NMS (keep iff score > 0 and no strictly greater neighbour; ties
+  // survive, src/orb_cpu.cpp:110-133) + survivor mask
+  u64* mrow = mask + (size_t)f * plan.mask_words + L.mask_off;
+#pragma unroll 1
+  for (int k = 0; k < ORBX_FAST_TH / 4; k++) {
+    const int iy = (tid >> 6) + 4 * k, ix = lane;
+    const int gy = y0 + iy;
+    const uint16_t* sc = s_score + (iy + r) * FAST_SC_PITCH + ix + r;
+    const int s = sc[0];
+    bool keep = s > 0;
+    if (keep) {
+      for (int dy = -r; dy <= r; dy++)
+        for (int dx = -r; dx <= r; dx++) keep = keep && !(sc[dy * FAST_SC_PITCH + dx] > s);
+    }
+    const u64 m = __ballot(keep);
+    if (lane == 0 && gy < L.h) mrow[(size_t)gy * L.mask_wpr + tx] = m;
+    if (WRITE_SCORES) {
+      const int gx = x0 + ix;
+      if (gy < L.h && gx < L.w) scores_dbg[(size_t)gy * L.w + gx] = (uint16_t)s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 4. ordered compaction of the survivor mask: one workgroup per (level,
+//    frame) walks the mask words in row-major order, a block-wide exclusive
+//    scan of popcounts gives every set bit its row-major rank, the first
+//    `cap` are written (src/orb_cpu.cpp:108-110 order and cap -- NOT the
+//    atomicAdd order of src/cuda/NMS.cu:123).
+__global__ __launch_bounds__(256) void k_compact(OrbxPlan plan, const u64* __restrict__ mask,
+                                                 orbx_keypoint* __restrict__ cand,
+                                                 int32_t* __restrict__ cand_count,
+                                                 int32_t* __restrict__ cand_total) {
+  __shared__ int s_wsum[4];
+  const int l = blockIdx.x, f = blockIdx.y;
+  const OrbxLevel& L = plan.L[l];
+  const u64* m = mask + (size_t)f * plan.mask_words + L.mask_off;
+  orbx_keypoint* out = cand + (size_t)f * plan.cand_total + L.cand_off;
+  const int nwords = L.h * L.mask_wpr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int base = 0;
+  for (int w0 = 0; w0 < nwords; w0 += 256) {
+    const int i = w0 + tid;
+    u64 v = i < nwords ? m[i] : 0ull;
+    const int c = __popcll(v);
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int s = s_wsum[k];
+      if (k < wave) woff += s;
+      tot += s;
+    }
+    int pos = base + woff + incl - c;
+    if (c && pos < L.cap) {
+      const int y = i / L.mask_wpr, xw = i - y * L.mask_wpr;
+      while (v && pos < L.cap) {
+        const int b = __ffsll((long long)v) - 1;
+        v &= v - 1;
+        orbx_keypoint kp;
+        kp.x = xw * 64 + b;
+        kp.y = y;
+        out[pos++] = kp;
+      }
+    }
+    base += tot;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    cand_total[f * plan.nlevels + l] = base;
+    cand_count[f * plan.nlevels + l] = base < L.cap ? base : L.cap;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 5. Harris response at the candidate keypoints (intent of
+//    src/cuda/HarrisScore.cu:23-89, DESIGN.md "Harris"): float Sobel with
+//    REFLECT_101, window x window Gaussian of Ix^2, IxIy, Iy^2 accumulated in
+//    (i,j) row-major order, R = (AC - B^2) - (k*(A+C))*(A+C).
+//    Evaluated only in the (window+2)^2 neighbourhood of each candidate
+//    instead of 5 full-frame convolutions.
+__device__ __forceinline__ float harris_at(const uint8_t* img, int w, int h, int pitch, int x, int y,
+                                           const float* __restrict__ g, int K, float kk) {
+  const int r = K / 2;
+  float a = 0.f, b = 0.f, c = 0.f;
+  for (int i = 0; i < K; i++) {
+    const int yy = reflect101(y - r + i, h);
+    const uint8_t* r0 = img + (size_t)reflect101(yy - 1, h) * pitch;
+    const uint8_t* r1 = img + (size_t)yy * pitch;
+    const uint8_t* r2 = img + (size_t)reflect101(yy + 1, h) * pitch;
+    for (int j = 0; j < K; j++) {
+      const int xx = reflect101(x - r + j, w);
+      const int xl = reflect101(xx - 1, w), xr = reflect101(xx + 1, w);
+      const int p00 = r0[xl], p01 = r0[xx], p02 = r0[xr];
+      const int p10 = r1[xl], p12 = r1[xr];
+      const int p20 = r2[xl], p21 = r2[xx], p22 = r2[xr];
+      const float gx = (float)((p02 + 2 * p12 + p22) - (p00 + 2 * p10 + p20));
+      const float gy = (float)((p20 + 2 * p21 + p22) - (p00 + 2 * p01 + p02));
+      const float wgt = g[i * K + j];
+      a = __fadd_rn(a, __fmul_rn(__fmul_rn(gx, gx), wgt));
+      c = __fadd_rn(c, __fmul_rn(__fmul_rn(gy, gy), wgt));
+      b = __fadd_rn(b, __fmul_rn(__fmul_rn(gx, gy), wgt));
+    }
+  }
+  const float det = __fsub_rn(__fmul_rn(a, c), __fmul_rn(b, b));
+  const float trace = __fadd_rn(a, c);
+  return __fsub_rn(det, __fmul_rn(__fmul_rn(kk, trace), trace));
+}
+
+__global__ __launch_bounds__(256) void k_harris(OrbxPlan plan, const uint8_t* __restrict__ pyr,
+                                                const orbx_keypoint* __restrict__ cand,
+                                                const int32_t* __restrict__ cand_count,
+                                                const float* __restrict__ gauss, int K, float kk,
+                                                float* __restrict__ resp) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int f = blockIdx.y;
+  if (j >= plan.cand_total) return;
+  int l = 0;
+  for (int i = 1; i < plan.nlevels; i++)
+    if (j >= plan.L[i].cand_off) l = i;
+  const OrbxLevel& L = plan.L[l];
+  const int idx = j - L.cand_off;
+  if (idx >= cand_count[f * plan.nlevels + l]) return;
+  const orbx_keypoint kp = cand[(size_t)f * plan.cand_total + j];
+  const uint8_t* img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
+  resp[(size_t)f * plan.cand_total + j] = harris_at(img, L.w, L.h, L.pitch, kp.x, kp.y, gauss, K, kk);
+}
+
+__global__ __launch_bounds__(256) void k_harris_flat(const uint8_t* __restrict__ img, int w, int h, int pitch,
+                                                     const orbx_keypoint* __restrict__ kps, int nkp,
+                                                     const float* __restrict__ gauss, int K, float kk,
+                                                     float* __restrict__ resp) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= nkp) return;
+  resp[j] = harris_at(img, w, h, pitch, kps[j].x, kps[j].y, gauss, K, kk);
+}
+
+// ---------------------------------------------------------------------------
+// 6. per-level selection (src/orb.cpp:67-86 intent): rank every candidate by
+//    counting (response desc, index asc) -- a deterministic total order -- and
+//    scatter the first `quota` to the frame's result slots.  Levels are laid
+//    out back to back in level order (src/orb.cpp:100-102).
+__global__ __launch_bounds__(256) void k_select(OrbxPlan plan, int mode, const orbx_keypoint* __restrict__ cand,
+                                                const int32_t* __restrict__ cand_count,
+                                                const float* __restrict__ resp,
+                                                orbx_keypoint* __restrict__ out_lkp,
+                                                float* __restrict__ out_resp, int32_t* __restrict__ out_level,
+                                                int32_t* __restrict__ out_count) {
+  __shared__ float s_r[ORBX_MAX_SELECT];
+  const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  const OrbxLevel& L = plan.L[l];
+  const int n = cand_count[f * plan.nlevels + l];
+  const int keep = n < L.quota ? n : L.quota;
+  int out_off = 0;
+  for (int i = 0; i < l; i++) {
+    const int c = cand_count[f * plan.nlevels + i];
+    out_off += c < plan.L[i].quota ? c : plan.L[i].quota;
+  }
+  const orbx_keypoint* ck = cand + (size_t)f * plan.cand_total + L.cand_off;
+  const float* cr = resp + (size_t)f * plan.cand_total + L.cand_off;
+  orbx_keypoint* ok = out_lkp + (size_t)f * plan.out_cap + out_off;
+  float* orr = out_resp + (size_t)f * plan.out_cap + out_off;
+  int32_t* ol = out_level + (size_t)f * plan.out_cap + out_off;
+  if (mode == ORBX_SELECT_ROWMAJOR) {
+    for (int i = tid; i < keep; i += 256) {
+      ok[i] = ck[i];
+      orr[i] = 0.0f;
+      ol[i] = l;
+    }
+  } else {
+    for (int i = tid; i < n; i += 256) s_r[i] = cr[i];
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      const float ri = s_r[i];
+      int rank = 0;
+      for (int j = 0; j < n; j++) {
+        const float rj = s_r[j];
+        rank += (rj > ri) || (rj == ri && j < i);
+      }
+      if (rank < keep) {
+        ok[rank] = ck[i];
+        orr[rank] = ri;
+        ol[rank] = l;
+      }
+    }
+  }
+  if (l == plan.nlevels - 1 && tid == 0) out_count[f] = out_off + keep;
+}
+
+__global__ __launch_bounds__(256) void k_select_flat(const float* __restrict__ resp, int n, int keep,
+                                                     int32_t* __restrict__ idx) {
+  const int m = n < keep ? n : keep;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float ri = resp[i];
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+      const float rj = resp[j];
+      rank += (rj > ri) || (rj == ri && j < i);
+    }
+    if (rank < m) idx[rank] = i;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 7. orientation + rotated BRIEF-256, one wavefront per keypoint
+//    (src/orb_cpu.cpp:139-258; src/cuda/Orientations.cu:22-63,
+//    src/cuda/Brief.cu:40-95).
+//    The 41x41 neighbourhood (pattern radius 18 + 5x5 box radius 2, and the
+//    orientation patch) is loaded once into LDS with aligned dword loads,
+//    zero-filled outside the image.  Moments are exact int32 reduced across
+//    the wave; each lane then evaluates 4 of the 256 tests with 5x5 box sums
+//    taken straight from the u8 patch (exact integers, no integral image),
+//    and 4 ballots assemble the descriptor.
+#define DESC_R 20
+#define DESC_ROWS (2 * DESC_R + 1)  // 41
+#define DESC_PITCH 48               // bytes per LDS patch row (12 dwords)
+
+struct DescJob {
+  const uint8_t* img;
+  int w, h, pitch;
+  int x, y;
+  bool valid;
+};
+
+__device__ __forceinline__ void describe_wave(const DescJob& jb, uint8_t* s_patch, int patch_size,
+                                              bool use_given_angle, float given_angle, bool do_brief,
+                                              float& angle_out, u64 desc_out[4]) {
+  const int lane = lane_id();
+  uint32_t* s32 = reinterpret_cast<uint32_t*>(s_patch);
+  const int px0 = jb.x - DESC_R, py0 = jb.y - DESC_R;
+  const int ax0 = px0 & ~3;  // floor to a multiple of 4 (two's complement)
+  const int off = px0 - ax0;
+  if (jb.valid) {
+    for (int i = lane; i < DESC_ROWS * (DESC_PITCH / 4); i += 64) {
+      const int row = i / (DESC_PITCH / 4), c = i - row * (DESC_PITCH / 4);
+      const int gy = py0 + row, gx = ax0 + 4 * c;
+      uint32_t v = 0;
+      if (gy >= 0 && gy < jb.h && gx >= 0 && gx + 4 <= jb.pitch)
+        v = *reinterpret_cast<const uint32_t*>(jb.img + (size_t)gy * jb.pitch + gx);
+      s32[i] = v;
+    }
+  }
+  __syncthreads();
+  float angle = 0.0f;
+  if (jb.valid) {
+    if (use_given_angle) {
+      angle = given_angle;
+    } else {
+      const int pr = patch_size / 2, P = 2 * pr + 1;
+      // full patch must lie inside the image, else 0 (src/orb_cpu.cpp:152-156)
+      if (!(jb.x - pr < 0 || jb.x + pr >= jb.w || jb.y - pr < 0 || jb.y + pr >= jb.h)) {
+        int m10 = 0, m01 = 0;
+        for (int i = lane; i < P * P; i += 64) {
+          const int rr = i / P, cc = i - rr * P;
+          const int I = s_patch[(rr - pr + DESC_R) * DESC_PITCH + (cc - pr + DESC_R + off)];
+          m10 += (cc - pr) * I;
+          m01 += (rr - pr) * I;
+        }
+        m10 = wave_sum(m10);
+        m01 = wave_sum(m01);
+        // the reference accumulates in float; every partial sum is an integer
+        // below 2^24, hence exact, hence equal to this int32 sum
+        angle = orbx_atan2f((float)m01, (float)m10);
+      }
+    }
+  }
+  angle_out = angle;
+  if (!do_brief) return;
+  const float c = orbx_cosf(angle), s = orbx_sinf(angle);
+#pragma unroll 1
+  for (int k = 0; k < 4; k++) {
+    bool bit = false;
+    if (jb.valid) {
+      const int i = k * 64 + lane;
+      const float x1 = (float)c_pattern[i * 4], y1 = (float)c_pattern[i * 4 + 1];
+      const float x2 = (float)c_pattern[i * 4 + 2], y2 = (float)c_pattern[i * 4 + 3];
+      // lround(c*x - s*y), lround(s*x + c*y): separate IEEE mul / add-sub,
+      // round half away from zero (src/orb_cpu.cpp:228-232)
+      int dx1 = orbx_lroundf(__fsub_rn(__fmul_rn(c, x1), __fmul_rn(s, y1)));
+      int dy1 = orbx_lroundf(__fadd_rn(__fmul_rn(s, x1), __fmul_rn(c, y1)));
+      int dx2 = orbx_lroundf(__fsub_rn(__fmul_rn(c, x2), __fmul_rn(s, y2)));
+      int dy2 = orbx_lroundf(__fadd_rn(__fmul_rn(s, x2), __fmul_rn(c, y2)));
+      const int cx1 = jb.x + dx1, cy1 = jb.y + dy1, cx2 = jb.x + dx2, cy2 = jb.y + dy2;
+      // bounds check of the reference, in image terms: integral width-2 ==
+      // cols-1 (src/orb_cpu.cpp:240-245)
+      const bool skip = cx1 < 2 || cy1 < 2 || cx1 > jb.w - 1 || cy1 > jb.h - 1 || cx2 < 2 || cy2 < 2 ||
+                        cx2 > jb.w - 1 || cy2 > jb.h - 1;
+      if (!skip) {
+        // memory safety for angles outside the documented domain
+        dx1 = min(max(dx1, -18), 18);
+        dy1 = min(max(dy1, -18), 18);
+        dx2 = min(max(dx2, -18), 18);
+        dy2 = min(max(dy2, -18), 18);
+        const uint8_t* p1 = s_patch + (dy1 + DESC_R - 2) * DESC_PITCH + (dx1 + DESC_R + off - 2);
+        const uint8_t* p2 = s_patch + (dy2 + DESC_R - 2) * DESC_PITCH + (dx2 + DESC_R + off - 2);
+        int s1 = 0, s2 = 0;
+#pragma unroll
+        for (int yy = 0; yy < 5; yy++)
+#pragma unroll
+          for (int xx = 0; xx < 5; xx++) {
+            s1 += p1[yy * DESC_PITCH + xx];
+            s2 += p2[yy * DESC_PITCH + xx];
+          }
+        bit = s1 < s2;
+      }
+    }
+    desc_out[k] = __ballot(bit);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_describe(OrbxPlan plan, const uint8_t* __restrict__ pyr, int patch_size,
+                                                  const int32_t* __restrict__ out_count,
+                                                  const orbx_keypoint* __restrict__ out_lkp,
+                                                  const int32_t* __restrict__ out_level,
+                                                  orbx_keypoint* __restrict__ out_kp,
+                                                  float* __restrict__ out_angle,
+                                                  orbx_descriptor* __restrict__ out_desc) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][DESC_ROWS * DESC_PITCH];
+  const int f = blockIdx.y, wave = threadIdx.x >> 6;
+  const int slot = blockIdx.x * 4 + wave;
+  const int count = out_count[f];
+  DescJob jb;
+  jb.valid = slot < count;
+  int l = 0;
+  orbx_keypoint kp = {0, 0};
+  if (jb.valid) {
+    kp = out_lkp[(size_t)f * plan.out_cap + slot];
+    l = out_level[(size_t)f * plan.out_cap + slot];
+  }
+  const OrbxLevel& L = plan.L[l];
+  jb.img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
+  jb.w = L.w;
+  jb.h = L.h;
+  jb.pitch = L.pitch;
+  jb.x = kp.x;
+  jb.y = kp.y;
+  float angle;
+  u64 d[4];
+  describe_wave(jb, s_patch[wave], patch_size, false, 0.0f, true, angle, d);
+  if (jb.valid && lane_id() == 0) {
+    const size_t o = (size_t)f * plan.out_cap + slot;
+    out_angle[o] = angle;
+    orbx_keypoint g;  // kp.x *= scale on int (src/orb.cpp:94-98)
+    g.x = (int)__fmul_rn((float)kp.x, L.scale);
+    g.y = (int)__fmul_rn((float)kp.y, L.scale);
+    out_kp[o] = g;
+    u64* dd = reinterpret_cast<u64*>(out_desc + o);
+    dd[0] = d[0];
+    dd[1] = d[1];
+    dd[2] = d[2];
+    dd[3] = d[3];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_describe_flat(const uint8_t* __restrict__ img, int w, int h, int pitch,
+                                                       const orbx_keypoint* __restrict__ kps, int nkp,
+                                                       int patch_size, int use_given_angles, int do_brief,
+                                                       float* __restrict__ angles,
+                                                       orbx_descriptor* __restrict__ desc) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][DESC_ROWS * DESC_PITCH];
+  const int wave = threadIdx.x >> 6;
+  const int slot = blockIdx.x * 4 + wave;
+  DescJob jb;
+  jb.valid = slot < nkp;
+  jb.img = img;
+  jb.w = w;
+  jb.h = h;
+  jb.pitch = pitch;
+  jb.x = jb.valid ? kps[slot].x : 0;
+  jb.y = jb.valid ? kps[slot].y : 0;
+  const float given = (jb.valid && use_given_angles) ? angles[slot] : 0.0f;
+  float angle;
+  u64 d[4];
+  describe_wave(jb, s_patch[wave], patch_size, use_given_angles != 0, given, do_brief != 0, angle, d);
+  if (jb.valid && lane_id() == 0) {
+    if (!use_given_angles) angles[slot] = angle;
+    if (do_brief) {
+      u64* dd = reinterpret_cast<u64*>(desc + slot);
+      dd[0] = d[0];
+      dd[1] = d[1];
+      dd[2] = d[2];
+      dd[3] = d[3];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// stage-level helpers (not on the batched hot path)
+
+// thresholded NMS of an arbitrary float score map (src/cuda/NMS.cu:21-128):
+// border of width r rejected, val > threshold, no strictly greater neighbour.
+__global__ __launch_bounds__(256) void k_nms_f32(const float* __restrict__ scores, int w, int h, int r,
+                                                 float threshold, u64* __restrict__ mask, int mask_wpr) {
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  bool keep = false;
+  if (y < h && x < w && !(x < r || y < r || x >= w - r || y >= h - r)) {
+    const float v = scores[(size_t)y * w + x];
+    keep = v > threshold;
+    if (keep)
+      for (int dy = -r; dy <= r; dy++)
+        for (int dx = -r; dx <= r; dx++) keep = keep && !(scores[(size_t)(y + dy) * w + (x + dx)] > v);
+  }
+  const u64 m = __ballot(keep);
+  if ((threadIdx.x & 63) == 0 && y < h) mask[(size_t)y * mask_wpr + blockIdx.x] = m;
+}
+
+// generic KxK correlation (src/cuda/Convolution.cu:20-55 arithmetic: float
+// accumulate in (i,j) row-major order) with the wrapper's CV_8U conversion
+// (round-half-even + saturate, :100).  reflect_pad=0: valid correlation of a
+// pre-padded image; reflect_pad=1: output same size, REFLECT_101 borders
+// (== copyMakeBorder + conv2d, src/GaussianBlur.cpp:44-46, src/Sobel.cpp:29-31).
+__global__ __launch_bounds__(256) void k_conv2d(const uint8_t* __restrict__ img, int w, int h, int pitch,
+                                                const float* __restrict__ kern, int K, int reflect_pad,
+                                                uint8_t* __restrict__ dst, int dst_pitch) {
+  const int wo = reflect_pad ? w : w - K + 1, ho = reflect_pad ? h : h - K + 1;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= wo || y >= ho) return;
+  const int r = K / 2;
+  float sum = 0.f;
+  for (int i = 0; i < K; i++)
+    for (int j = 0; j < K; j++) {
+      int yy, xx;
+      if (reflect_pad) {
+        yy = reflect101(y - r + i, h);
+        xx = reflect101(x - r + j, w);
+      } else {
+        yy = y + i;
+        xx = x + j;
+      }
+      sum = __fadd_rn(sum, __fmul_rn((float)img[(size_t)yy * pitch + xx], kern[i * K + j]));
+    }
+  int v = __float2int_rn(sum);
+  v = v < 0 ? 0 : (v > 255 ? 255 : v);
+  dst[(size_t)y * dst_pitch + x] = (uint8_t)v;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+
+#define ORBX_LAUNCH_CHECK() hipGetLastError()
+
+hipError_t orbx_launch_pyramid(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
+                               const uint8_t* d_in, int in_stride, size_t in_frame_stride,
+                               const OrbxResizeTap* d_taps, uint8_t* d_pyr) {
+  dim3 grid(tm.begin[plan.nlevels], n_frames);
+  hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, s, plan, tm, d_in, in_stride, in_frame_stride, d_taps, d_pyr);
+  return ORBX_LAUNCH_CHECK();
+}
+
+hipError_t orbx_launch_blur(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
+                            const uint8_t* d_src, uint8_t* d_dst, int first_level, int kind) {
+  dim3 grid(tm.begin[plan.nlevels], n_frames);
+  hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, s, plan, tm, d_src, d_dst, first_level, kind);
+  return ORBX_LAUNCH_CHECK();
+}
+
+hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
+                                const uint8_t* d_pyr, OrbxFastParams fp, unsigned long long* d_mask,
+                                uint16_t* d_scores_dbg) {
+  dim3 grid(tm.begin[plan.nlevels], n_frames);
+  if (d_scores_dbg)
+    hipLaunchKernelGGL(k_fast_nms<true>, grid, dim3(256), 0, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+  else
+    hipLaunchKernelGGL(k_fast_nms<false>, grid, dim3(256), 0, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+  return ORBX_LAUNCH_CHECK();
+}
+
+hipError_t orbx_launch_compact(hipStream_t s, const OrbxPlan& plan, int n_frames,
+                               const unsigned long long* d_mask, orbx_keypoint* d_cand, int32_t* d_cand_count,
+                               int32_t* d_cand_total) {
+  dim3 grid(plan.nlevels, n_frames);
+  hipLaunchKernelGGL(k_compact, grid, dim3(256), 0, s, plan, d_mask, d_cand, d_cand_count, d_cand_total);
+  return ORBX_LAUNCH_CHECK();
+}
+
+hipError_t orbx_launch_harris(hipStream_t s, const OrbxPlan& plan, int n_frames, const uint8_t* d_pyr,
+                              const orbx_keypoint* d_cand, const int32_t* d_cand_count, const float* d_gauss,
+                              int window, float k, float* d_resp) {
+  if (plan.cand_total <= 0) return hipSuccess;
+  dim3 grid((plan.cand_total + 255) / 256, n_frames);
+  hipLaunchKernelGGL(k_harris, grid, dim3(256), 0, s, plan, d_pyr, d_cand, d_cand_count, d_gauss, window, k,
+                     d_resp);
+  return ORBX_LAUNCH_CHECK();
+}
+
+hipError_t orbx_launch_select(hipStream_t s, const OrbxPlan& plan, int n_frames, int mode,
+                              const orbx_keypoint* d_cand, const int32_t* d_cand_count, const float* d_resp,
+                              orbx_keypoint* d_out_lkp, float* d_out_resp, int32_t* d_out_level,
+                              int32_t* d_out_count) {
+  dim3 grid(plan.nlevels, n_frames);
+  hipLaunchKernelGGL(k_select, grid, dim3(256), 0, s, plan, mode, d_cand, d_cand_count, d_resp, d_out_lkp,
+                     d_out_resp, d_out_level, d_out_count);
+  return ORBX_LAUNCH_CHECK();
+}
+
+hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frames, const uint8_t* d_pyr,
+                                int patch_size, const int32_t* d_out_count, const orbx_keypoint* d_out_lkp,
+                                const int32_t* d_out_level, orbx_keypoint* d_out_kp, float* d_out_angle,
+                                orbx_descriptor* d_out_desc) {
+  if (plan.out_cap <= 0) return hipSuccess;
+  dim3 grid((plan.out_cap + 3) / 4, n_frames);
+  hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_out_count, d_out_lkp,
+                     d_out_level, d_out_kp, d_out_angle, d_out_desc);
+  return ORBX_LAUNCH_CHECK();
+}
+
+hipError_t orbx_launch_describe_flat(hipStream_t s, const uint8_t* d_img, int w, int h, int pitch,
+                                     const orbx_keypoint* d_kps, int nkp, int patch_size, int use_given_angles,
+                                     int do_brief, float* d_angles, orbx_descriptor* d_desc) {
+  if (nkp <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_describe_flat, dim3((nkp + 3) / 4), dim3(256), 0, s, d_img, w, h, pitch, d_kps, nkp,
+                     patch_size, use_given_angles, do_brief, d_angles, d_desc);
+  return ORBX_LAUNCH_CHECK();
+}
+
+hipError_t orbx_launch_harris_flat(hipStream_t s, const uint8_t* d_img, int w, int h, int pitch,
+                                   const orbx_keypoint* d_kps, int nkp, const float* d_gauss, int K, float kk,
+                                   float* d_resp) {
+  if (nkp <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_harris_flat, dim3((nkp + 255) / 256), dim3(256), 0, s, d_img, w, h, pitch, d_kps, nkp,
+                     d_gauss, K, kk, d_resp);
+  return ORBX_LAUNCH_CHECK();
+}
+
+hipError_t orbx_launch_nms_f32(hipStream_t s, const float* d_scores, int w, int h, int radius, float threshold,
+                               unsigned long long* d_mask, int mask_wpr) {
+  dim3 grid((w + 63) / 64, (h + 3) / 4);
+  hipLaunchKernelGGL(k_nms_f32, grid, dim3(256), 0, s, d_scores, w, h, radius, threshold, d_mask, mask_wpr);
+  return ORBX_LAUNCH_CHECK();
+}
+
+hipError_t orbx_launch_conv2d(hipStream_t s, const uint8_t* d_img, int w, int h, int pitch, const float* d_kernel,
+                              int K, int reflect_pad, uint8_t* d_dst, int dst_pitch) {
+  const int wo = reflect_pad ? w : w - K + 1, ho = reflect_pad ? h : h - K + 1;
+  if (wo <= 0 || ho <= 0) return hipSuccess;
+  dim3 grid((wo + 63) / 64, (ho + 3) / 4);
+  hipLaunchKernelGGL(k_conv2d, grid, dim3(256), 0, s, d_img, w, h, pitch, d_kernel, K, reflect_pad, d_dst,
+                     dst_pitch);
+  return ORBX_LAUNCH_CHECK();
+}
+
+hipError_t orbx_launch_select_flat(hipStream_t s, const float* d_resp, int n, int keep, int32_t* d_idx) {
+  if (n <= 0) return hipSuccess;
+  int blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_select_flat, dim3(blocks), dim3(256), 0, s, d_resp, n, keep, d_idx);
+  return ORBX_LAUNCH_CHECK();
+}
