@@ -110,22 +110,22 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    pkg = importlib.import_module("visual-odometry-gpu_amd")
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
-    pkg = importlib.import_module("visual-odometry-gpu_amd")
     B = args.batch
     if args.workload == "kitti":
         H, W = 376, 1241
         pk = dict(nfeatures=1000, nlevels=8, scale_factor=1.2, threshold=20, n=9, nms_window=3, patch_size=31,
                   blur_levels=2, blur_kind=0)
-        frames = stream_a(B, first=rank * B)
+        frames = stream_a(B, first=pkg.shard.frame_range(rank, world, B)[0])
         wl = "KITTI-shaped 1241x376 u8, 8 levels s=1.2, 1000 features, FAST-9 t=20, NMS 3x3, Harris top-N, blur5 all levels, BRIEF-256; batch=%d frames/step/GPU resident in HBM (stream A)" % B
     else:
         H, W = 1080, 1920
         pk = dict(nfeatures=4000, nlevels=12, scale_factor=1.2, threshold=20, n=9, nms_window=3, patch_size=31,
                   blur_levels=2, blur_kind=0)
-        frames = stream_b(B, H, W, first=rank * B)
+        frames = stream_b(B, H, W, first=pkg.shard.frame_range(rank, world, B)[0])
         wl = "1920x1080 u8, 12 levels, 4000 features, Harris+NMS; batch=%d (stream B)" % B
 
     p = pkg.default_params("gpu", max_width=W, max_height=H, max_batch=B, device=local_rank, **pk)
@@ -135,10 +135,11 @@ def main():
     d_frames = torch.from_numpy(frames).cuda()
     torch.cuda.synchronize()
 
+    grp = pkg.shard.Group(world, device=torch.device("cuda", local_rank))
+
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        grp.barrier()
         torch.cuda.synchronize()
 
     def step():
@@ -160,10 +161,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ctx.enable_stage_timing(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = grp.max_float(dt)
     for k in stage_ms:
         stage_ms[k] /= max(args.steps, 1)
 
@@ -176,12 +174,8 @@ def main():
     dt_d2h = (time.perf_counter() - t1) / max(1, min(args.steps, 5))
 
     # result checksum: same answer on every run / rank layout (frames are rank-specific)
-    n_kp = int(res["counts"].sum())
-    csum = int(np.bitwise_xor.reduce(res["desc"].reshape(-1, 32).view(np.uint64).ravel())) & 0xFFFFFFFF
-    if world > 1:
-        t = torch.tensor([n_kp], dtype=torch.int64, device="cuda")
-        dist.all_reduce(t)
-        n_kp = int(t.item())
+    n_kp = grp.sum_int(int(res["counts"].sum()))
+    csum = grp.sum_checksum(pkg.shard.descriptor_checksum(res["counts"], res["desc"]))
 
     if rank == 0:
         fps = world * B * args.steps / dt
@@ -205,7 +199,7 @@ def main():
                                             "algorithmic_bytes_per_step": alg["blur"] + alg["fast_nms"]}},
             "stage_ms_per_step": stage_ms,
             "fps_with_d2h": world * B / dt_d2h,
-            "keypoints_per_step": n_kp, "desc_checksum_rank0": csum,
+            "keypoints_per_step": n_kp, "desc_checksum": csum,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, pk) if args.workload == "kitti" else None
