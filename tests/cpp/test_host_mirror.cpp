@@ -1,0 +1,149 @@
+// test_host_mirror.cpp -- the reference's scratch harness src/compare.cpp
+// (:39-62, :82-107: "for every CPU keypoint look up the GPU keypoint at the same
+// (x,y) and print the Hamming distance of the descriptors") turned into a real
+// test of the C++ host mirror (visual-odometry-gpu_amd/host/orb.hpp), with the
+// CPU oracle as the checker.  Usage: test_host_mirror <raw-u8-file> <w> <h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <utility>
+
+#include "../../oracle/orb_oracle.h"
+#include "../../visual-odometry-gpu_amd/host/orb.hpp"
+
+static int fails = 0;
+#define EXPECT(cond, ...)                        \
+  do {                                           \
+    if (!(cond)) {                               \
+      std::printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+      std::printf(__VA_ARGS__);                  \
+      std::printf("\n");                         \
+      fails++;                                   \
+    }                                            \
+  } while (0)
+
+static int hamming(const uint8_t* a, const uint8_t* b, const uint8_t* mask) {
+  int d = 0;
+  for (int i = 0; i < 32; i++) d += __builtin_popcount((unsigned)((a[i] ^ b[i]) & mask[i]));
+  return d;
+}
+
+int main(int argc, char** argv) {
+  if (argc != 4) return 2;
+  const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
+  std::vector<uint8_t> px((size_t)w * h);
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f || std::fread(px.data(), 1, px.size(), f) != px.size()) return 2;
+  std::fclose(f);
+  orbx::Image image(px.data(), w, h);
+
+  // ---- ORBCPU twin vs oracle (compare.cpp:40 `orb_cpu.detectAndCompute`)
+  {
+    ORBCPU orb_cpu;
+    std::vector<Keypoint> kps;
+    std::vector<float> angles;
+    std::vector<ORBDescriptor> descs;
+    orb_cpu.detectAndCompute(image, kps, angles, descs);
+    std::vector<int32_t> okp(2 * 3000);
+    std::vector<float> oang(3000);
+    std::vector<uint8_t> odesc(32 * 3000), ovalid(32 * 3000);
+    const int n = oracle_detect_and_compute_cpu(px.data(), w, h, w, 3000, 50, 9, 3, 9, okp.data(), oang.data(),
+                                                odesc.data(), ovalid.data());
+    EXPECT((int)kps.size() == n, "ORBCPU count %zu vs oracle %d", kps.size(), n);
+    std::map<std::pair<int, int>, int> gpu_map;  // compare.cpp:45-48
+    for (size_t i = 0; i < kps.size(); i++) gpu_map[{kps[i].x, kps[i].y}] = (int)i;
+    int not_found = 0, max_hd = 0;
+    for (int i = 0; i < n; i++) {  // compare.cpp:50-62
+      auto it = gpu_map.find({okp[2 * i], okp[2 * i + 1]});
+      if (it == gpu_map.end()) {
+        not_found++;
+        continue;
+      }
+      const int hd = hamming(descs[it->second].data, &odesc[32 * i], &ovalid[32 * i]);
+      if (hd > max_hd) max_hd = hd;
+      EXPECT(it->second == i, "keypoint order differs at %d", i);
+      EXPECT(std::memcmp(&angles[it->second], &oang[i], 4) == 0, "angle differs at %d", i);
+    }
+    EXPECT(not_found == 0, "%d oracle keypoints not found on the GPU", not_found);
+    EXPECT(max_hd == 0, "max Hamming distance %d", max_hd);
+    std::printf("ORBCPU: %zu keypoints, %d not found, max Hamming %d\n", kps.size(), not_found, max_hd);
+  }
+
+  // ---- ORB (GPU flavour, compare.cpp:65 `orb_gpu.detectAndCompute`) vs oracle intent
+  {
+    ORB orb_gpu(1000, 1.2f, 8);
+    std::vector<Keypoint> kps;
+    std::vector<float> angles, resp;
+    std::vector<ORBDescriptor> descs;
+    std::vector<int32_t> levels;
+    orb_gpu.detectAndCompute(image, kps, angles, descs, &resp, &levels);
+    // assign semantics: a second call must not append (D12)
+    orb_gpu.detectAndCompute(image, kps, angles, descs, &resp, &levels);
+    oracle_orb_params p = {1000, 1.2f, 8, 20, 9, 3, 31, 7, 0.04f, 0, 0};
+    const int cap = 1000;
+    std::vector<int32_t> okp(2 * cap), olkp(2 * cap), olev(cap);
+    std::vector<float> oang(cap), oresp(cap);
+    std::vector<uint8_t> odesc(32 * cap), ovalid(32 * cap);
+    const int n = oracle_detect_and_compute_gpu(px.data(), w, h, w, &p, okp.data(), olkp.data(), olev.data(),
+                                                oang.data(), oresp.data(), odesc.data(), ovalid.data(), cap);
+    EXPECT((int)kps.size() == n, "ORB count %zu vs oracle %d", kps.size(), n);
+    int bad = 0;
+    for (int i = 0; i < n && i < (int)kps.size(); i++) {
+      if (kps[i].x != okp[2 * i] || kps[i].y != okp[2 * i + 1] || levels[i] != olev[i]) bad++;
+      if (hamming(descs[i].data, &odesc[32 * i], &ovalid[32 * i]) != 0) bad++;
+      if (std::memcmp(&angles[i], &oang[i], 4) != 0) bad++;
+      if (std::memcmp(&resp[i], &oresp[i], 4) != 0) bad++;
+    }
+    EXPECT(bad == 0, "%d mismatching fields", bad);
+    std::printf("ORB: %zu keypoints over 8 levels, %d mismatches\n", kps.size(), bad);
+  }
+
+  // ---- sub-objects and free functions keep the reference call shapes
+  {
+    OrientedFAST fast;  // (20, 9, 3, 31)
+    std::vector<Keypoint> kps = fast.detect(image, 434);
+    std::vector<int32_t> okp(2 * 434);
+    const int n = oracle_fast_detect(px.data(), w, h, w, 20, 9, 3, 434, okp.data());
+    EXPECT((int)kps.size() == n && std::memcmp(kps.data(), okp.data(), sizeof(Keypoint) * n) == 0, "OrientedFAST::detect");
+    std::vector<float> ang = fast.compute_orientations(image, kps);
+    std::vector<float> oang(n);
+    oracle_orientations(px.data(), w, h, w, okp.data(), n, 31, oang.data());
+    EXPECT(std::memcmp(ang.data(), oang.data(), 4 * n) == 0, "compute_orientations");
+    RotatedBRIEF brief;
+    std::vector<ORBDescriptor> d = brief.compute(image, kps, ang);
+    std::vector<uint8_t> od(32 * n), ov(32 * n);
+    oracle_brief(px.data(), w, h, w, okp.data(), oang.data(), n, od.data(), ov.data(), nullptr, nullptr);
+    EXPECT(std::memcmp(d.data(), od.data(), 32 * n) == 0, "RotatedBRIEF::compute");
+    std::vector<float> hs;
+    HarrisScore(image, kps, hs, 7, 0.04f);
+    std::vector<float> ohs(n);
+    oracle_harris(px.data(), w, h, w, okp.data(), n, 7, 0.04f, ohs.data());
+    EXPECT(std::memcmp(hs.data(), ohs.data(), 4 * n) == 0, "HarrisScore");
+    orbx::Image8 b1, b2, b3, sx;
+    GaussianBlur1D(image, b1);
+    GaussianBlur(image, b2);
+    GaussianBlurCUDA(image, b3, 7);
+    SobelCUDA(image, sx, 0);
+    std::vector<uint8_t> o(px.size());
+    oracle_blur5_sep(px.data(), w, h, w, o.data(), w);
+    EXPECT(o == b1.pixels, "GaussianBlur1D");
+    oracle_blur5_273(px.data(), w, h, w, o.data(), w);
+    EXPECT(o == b2.pixels, "GaussianBlur");
+    oracle_gaussian_blur_conv(px.data(), w, h, w, 7, o.data());
+    EXPECT(o == b3.pixels, "GaussianBlurCUDA");
+    oracle_sobel_u8(px.data(), w, h, w, 0, o.data());
+    EXPECT(o == sx.pixels, "SobelCUDA");
+    // error behaviour: exceptions, never exit()
+    bool threw = false;
+    try {
+      std::vector<ORBDescriptor> dd;
+      Brief(image, kps, std::vector<float>(1), dd);
+    } catch (const std::runtime_error&) {
+      threw = true;
+    }
+    EXPECT(threw, "size mismatch must throw");
+  }
+  std::printf(fails ? "FAILED (%d)\n" : "OK\n", fails);
+  return fails ? 1 : 0;
+}

@@ -1,0 +1,377 @@
+// orb.hpp -- C++ host-side mirror of the reference's ORB interface, on top of
+// the liborbx C ABI (include/orbx.h).  Header-only, C++17, no OpenCV needed.
+//
+// Same class / function names, constructor defaults, argument meaning and
+// ownership as the reference, so code written against the reference headers
+// keeps compiling after `#include "orb.hpp"` is pointed here:
+//
+//   reference                                   this header
+//   ------------------------------------------  ---------------------------------
+//   include/orb.hpp:4      struct Keypoint       Keypoint (layout == orbx_keypoint)
+//   include/orb.hpp:6-8    struct ORBDescriptor  ORBDescriptor (== orbx_descriptor)
+//   include/orb.hpp:10-22  class OrientedFAST    OrientedFAST
+//   include/orb.hpp:24-32  class RotatedBRIEF    RotatedBRIEF
+//   include/orb.hpp:34-49  class ORB             ORB
+//   include/orb_cpu.hpp    *CPU twins            OrientedFASTCPU / RotatedBRIEFCPU / ORBCPU
+//                                                (same GPU kernels, CPU-flavour semantics)
+//   include/Fast.cuh:5-6   Fast, Orientations    Fast, Orientations
+//   include/NMS.cuh:5      NMS                   NMS
+//   include/HarrisScore.cuh:5  HarrisScore       HarrisScore
+//   include/Brief.cuh:5    Brief                 Brief
+//   include/Convolution.cuh:5  conv2d            conv2d
+//   include/GaussianBlur.cuh:3-4  GaussianBlur, GaussianBlur1D
+//   include/GaussianBlur.hpp:6  GaussianBlurCUDA GaussianBlurCUDA
+//   include/Sobel.hpp:6    SobelCUDA             SobelCUDA
+//
+// Differences, all deliberate:
+//   * images are passed as orbx::Image {data,width,height,stride}; a cv::Mat
+//     overload set is enabled with -DORBX_WITH_OPENCV when OpenCV exists;
+//   * ORB::detectAndCompute ASSIGNS its outputs like ORBCPU does
+//     (orb_cpu.cpp:272-275) instead of appending (orb.cpp:100-102, D12);
+//   * errors throw std::runtime_error (the reference prints and exit(1)s,
+//     Fast.cu:8-18) and constructors print nothing;
+//   * HarrisScore takes `float k` (the reference's `int k` truncates 0.04 to 0, D7).
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/orbx.h"
+
+#ifdef ORBX_WITH_OPENCV
+#include <opencv2/core.hpp>
+#endif
+
+struct Keypoint {
+  int x, y;
+};
+struct ORBDescriptor {
+  uint8_t data[32];
+};
+static_assert(sizeof(Keypoint) == sizeof(orbx_keypoint), "Keypoint layout");
+static_assert(sizeof(ORBDescriptor) == sizeof(orbx_descriptor), "ORBDescriptor layout");
+
+namespace orbx {
+
+// 8-bit single-channel image view (what the reference passes as CV_8UC1 cv::Mat)
+struct Image {
+  const uint8_t* data = nullptr;
+  int width = 0, height = 0, stride = 0;
+  Image() = default;
+  Image(const uint8_t* d, int w, int h, int s = 0) : data(d), width(w), height(h), stride(s ? s : w) {}
+#ifdef ORBX_WITH_OPENCV
+  Image(const cv::Mat& m) : data(m.data), width(m.cols), height(m.rows), stride((int)m.step) {  // NOLINT
+    if (m.type() != CV_8UC1) throw std::runtime_error("orbx: image must be CV_8UC1");  // CV_Assert, orb_cpu.cpp:26
+  }
+#endif
+};
+
+// owned 8-bit image (what the reference returns in a cv::Mat `dst`)
+struct Image8 {
+  std::vector<uint8_t> pixels;
+  int width = 0, height = 0;
+  Image view() const { return Image(pixels.data(), width, height, width); }
+};
+
+namespace detail {
+
+inline void check(orbx_ctx* c, int st, const char* what) {
+  if (st != ORBX_OK)
+    throw std::runtime_error(std::string(what) + ": " + orbx_status_string(st) + ": " + orbx_last_error_string(c));
+}
+
+// A context that grows with the largest image it has seen (the reference
+// allocates per call; here device memory is owned by the object).
+class Ctx {
+ public:
+  explicit Ctx(const orbx_params& p) : p_(p) {}
+  ~Ctx() { orbx_destroy(c_); }
+  Ctx(const Ctx&) = delete;
+  Ctx& operator=(const Ctx&) = delete;
+  orbx_ctx* get(int w, int h) {
+    if (!c_ || w > p_.max_width || h > p_.max_height) {
+      orbx_destroy(c_);
+      c_ = nullptr;
+      p_.max_width = w > p_.max_width ? w : p_.max_width;
+      p_.max_height = h > p_.max_height ? h : p_.max_height;
+      check(nullptr, orbx_create(&p_, &c_), "orbx_create");
+    }
+    return c_;
+  }
+  const orbx_params& params() const { return p_; }
+
+ private:
+  orbx_params p_;
+  orbx_ctx* c_ = nullptr;
+};
+
+inline orbx_params gpu_defaults() {
+  orbx_params p;
+  orbx_params_default_gpu(&p);
+  p.max_width = 8;
+  p.max_height = 8;
+  return p;
+}
+inline orbx_params cpu_defaults() {
+  orbx_params p;
+  orbx_params_default_cpu(&p);
+  p.max_width = 8;
+  p.max_height = 8;
+  return p;
+}
+inline std::shared_ptr<Ctx>& stage_ctx() {  // shared by the free stage functions
+  static std::shared_ptr<Ctx> c = std::make_shared<Ctx>(gpu_defaults());
+  return c;
+}
+inline orbx_keypoint* kp(std::vector<Keypoint>& v) { return reinterpret_cast<orbx_keypoint*>(v.data()); }
+inline const orbx_keypoint* kp(const std::vector<Keypoint>& v) {
+  return reinterpret_cast<const orbx_keypoint*>(v.data());
+}
+inline orbx_descriptor* ds(std::vector<ORBDescriptor>& v) { return reinterpret_cast<orbx_descriptor*>(v.data()); }
+
+}  // namespace detail
+}  // namespace orbx
+
+// ---- free stage functions (reference: include/*.cuh, *.hpp) -----------------
+
+// Fast.cuh:5 -- returns the keypoint count; `keypoints` is resized to it.
+inline int Fast(const orbx::Image& image, std::vector<Keypoint>& keypoints, int threshold, int n, int nms_window,
+                int nfeatures) {
+  orbx_ctx* c = orbx::detail::stage_ctx()->get(image.width, image.height);
+  keypoints.resize(nfeatures > 0 ? nfeatures : 0);
+  int count = 0;
+  orbx::detail::check(c,
+                      orbx_fast(c, image.data, image.width, image.height, image.stride, threshold, n, nms_window,
+                                nfeatures, orbx::detail::kp(keypoints), &count, nullptr),
+                      "Fast");
+  keypoints.resize(count);
+  return count;
+}
+
+// Fast.cuh:6
+inline void Orientations(const orbx::Image& image, const std::vector<Keypoint>& keypoints,
+                         std::vector<float>& orientations, int patch_size) {
+  orbx_ctx* c = orbx::detail::stage_ctx()->get(image.width, image.height);
+  orientations.assign(keypoints.size(), 0.0f);
+  orbx::detail::check(c,
+                      orbx_orientations(c, image.data, image.width, image.height, image.stride,
+                                        orbx::detail::kp(keypoints), (int)keypoints.size(), patch_size,
+                                        orientations.data()),
+                      "Orientations");
+}
+
+// NMS.cuh:5 -- `scores` is a width*height float map (CV_32F in the reference)
+inline void NMS(const float* scores, int width, int height, std::vector<Keypoint>& keypoints, int nms_window,
+                int nfeatures, float threshold) {
+  orbx_ctx* c = orbx::detail::stage_ctx()->get(width < 8 ? 8 : width, height < 8 ? 8 : height);
+  keypoints.resize(nfeatures > 0 ? nfeatures : 0);
+  int count = 0;
+  orbx::detail::check(
+      c, orbx_nms(c, scores, width, height, nms_window, nfeatures, threshold, orbx::detail::kp(keypoints), &count, nullptr),
+      "NMS");
+  keypoints.resize(count);
+}
+
+// HarrisScore.cuh:5
+inline void HarrisScore(const orbx::Image& image, std::vector<Keypoint>& keypoints, std::vector<float>& harris_scores,
+                        int corner_window, float k) {
+  orbx_ctx* c = orbx::detail::stage_ctx()->get(image.width, image.height);
+  harris_scores.assign(keypoints.size(), 0.0f);
+  orbx::detail::check(c,
+                      orbx_harris(c, image.data, image.width, image.height, image.stride, orbx::detail::kp(keypoints),
+                                  (int)keypoints.size(), corner_window, k, harris_scores.data()),
+                      "HarrisScore");
+}
+
+// Brief.cuh:5 -- n_bits must be 256 and patch_size 31, as in the reference
+inline void Brief(const orbx::Image& image, const std::vector<Keypoint>& keypoints,
+                  const std::vector<float>& orientations, std::vector<ORBDescriptor>& descriptors, int n_bits = 256,
+                  int patch_size = 31) {
+  if (n_bits != 256 || patch_size != 31) throw std::runtime_error("Brief: only n_bits=256, patch_size=31 exist");
+  if (orientations.size() != keypoints.size()) throw std::runtime_error("Brief: size mismatch");
+  orbx_ctx* c = orbx::detail::stage_ctx()->get(image.width, image.height);
+  descriptors.assign(keypoints.size(), ORBDescriptor{});
+  orbx::detail::check(c,
+                      orbx_brief(c, image.data, image.width, image.height, image.stride, orbx::detail::kp(keypoints),
+                                 orientations.data(), (int)keypoints.size(), orbx::detail::ds(descriptors)),
+                      "Brief");
+}
+
+// Convolution.cuh:5 -- `image` is pre-padded; dst is (h-K+1) x (w-K+1)
+inline void conv2d(const orbx::Image& image, orbx::Image8& dst, const float* kernel, int kernel_size) {
+  orbx_ctx* c = orbx::detail::stage_ctx()->get(image.width, image.height);
+  dst.width = image.width - kernel_size + 1;
+  dst.height = image.height - kernel_size + 1;
+  if (dst.width < 1 || dst.height < 1) throw std::runtime_error("conv2d: image smaller than kernel");
+  dst.pixels.assign((size_t)dst.width * dst.height, 0);
+  orbx::detail::check(
+      c, orbx_conv2d(c, image.data, image.width, image.height, image.stride, kernel, kernel_size, dst.pixels.data()),
+      "conv2d");
+}
+
+namespace orbx::detail {
+template <class F>
+inline void same_size_stage(const Image& image, Image8& dst, const char* what, F&& call) {
+  orbx_ctx* c = stage_ctx()->get(image.width, image.height);
+  dst.width = image.width;
+  dst.height = image.height;
+  dst.pixels.assign((size_t)dst.width * dst.height, 0);
+  check(c, call(c), what);
+}
+}  // namespace orbx::detail
+
+// GaussianBlur.cuh:3 (5x5 /273)
+inline void GaussianBlur(const orbx::Image& image, orbx::Image8& dst) {
+  orbx::detail::same_size_stage(image, dst, "GaussianBlur", [&](orbx_ctx* c) {
+    return orbx_blur5_273(c, image.data, image.width, image.height, image.stride, dst.pixels.data(), dst.width);
+  });
+}
+// GaussianBlur.cuh:4 (separable [1 4 6 4 1]/16)
+inline void GaussianBlur1D(const orbx::Image& image, orbx::Image8& dst) {
+  orbx::detail::same_size_stage(image, dst, "GaussianBlur1D", [&](orbx_ctx* c) {
+    return orbx_blur5_sep(c, image.data, image.width, image.height, image.stride, dst.pixels.data(), dst.width);
+  });
+}
+// GaussianBlur.hpp:6
+inline void GaussianBlurCUDA(const orbx::Image& image, orbx::Image8& dst, int kernel_size) {
+  orbx::detail::same_size_stage(image, dst, "GaussianBlurCUDA", [&](orbx_ctx* c) {
+    return orbx_gaussian_blur_conv(c, image.data, image.width, image.height, image.stride, kernel_size,
+                                   dst.pixels.data());
+  });
+}
+// Sobel.hpp:6
+inline void SobelCUDA(const orbx::Image& image, orbx::Image8& dst, int dir) {
+  orbx::detail::same_size_stage(image, dst, "SobelCUDA", [&](orbx_ctx* c) {
+    return orbx_sobel(c, image.data, image.width, image.height, image.stride, dir, dst.pixels.data());
+  });
+}
+
+// ---- classes (reference: include/orb.hpp, include/orb_cpu.hpp) ---------------
+
+class OrientedFAST {
+ public:
+  OrientedFAST(int threshold = 20, int n = 9, int nms_window = 3, int patch_size = 31)
+      : threshold(threshold), n(n), nms_window(nms_window), patch_size(patch_size) {}
+  // orb.cpp:22-27
+  std::vector<Keypoint> detect(const orbx::Image& image, int nfeatures) {
+    std::vector<Keypoint> keypoints;
+    Fast(image, keypoints, threshold, n, nms_window, nfeatures);
+    return keypoints;
+  }
+  // orb.cpp:29-33
+  std::vector<float> compute_orientations(const orbx::Image& image, const std::vector<Keypoint>& keypoints) {
+    std::vector<float> orientations;
+    Orientations(image, keypoints, orientations, patch_size);
+    return orientations;
+  }
+
+ private:
+  int threshold, n, nms_window, patch_size;
+};
+
+class RotatedBRIEF {
+ public:
+  RotatedBRIEF() = default;
+  // orb.cpp:40-44
+  std::vector<ORBDescriptor> compute(const orbx::Image& image, const std::vector<Keypoint>& keypoints,
+                                     const std::vector<float>& orientations) {
+    std::vector<ORBDescriptor> descriptors;
+    Brief(image, keypoints, orientations, descriptors, n_bits, patch_size);
+    return descriptors;
+  }
+
+ private:
+  int n_bits = 256;
+  int patch_size = 31;
+};
+
+class ORB {
+ public:
+  // orb.hpp:36; the FAST/Harris knobs the reference hard-codes are exposed through params()
+  ORB(int nfeatures = 500, float scaleFactor = 1.2f, int nlevels = 8) : ctx_(make(nfeatures, scaleFactor, nlevels)) {}
+  explicit ORB(const orbx_params& p) : ctx_(std::make_shared<orbx::detail::Ctx>(p)) {}
+
+  // orb.hpp:37 / orb.cpp:58-109.  Outputs are assigned (not appended).
+  void detectAndCompute(const orbx::Image& image, std::vector<Keypoint>& keypoints, std::vector<float>& orientations,
+                        std::vector<ORBDescriptor>& descriptors) {
+    detectAndCompute(image, keypoints, orientations, descriptors, nullptr, nullptr);
+  }
+  // extended form: Harris responses and pyramid level per keypoint
+  void detectAndCompute(const orbx::Image& image, std::vector<Keypoint>& keypoints, std::vector<float>& orientations,
+                        std::vector<ORBDescriptor>& descriptors, std::vector<float>* responses,
+                        std::vector<int32_t>* levels) {
+    orbx_ctx* c = ctx_->get(image.width, image.height);
+    int32_t cap = 0;
+    orbx::detail::check(c, orbx_get_plan(c, image.width, image.height, nullptr, nullptr, nullptr, nullptr, nullptr, &cap),
+                        "orbx_get_plan");
+    if (cap < 1) cap = 1;
+    keypoints.resize(cap);
+    orientations.resize(cap);
+    descriptors.resize(cap);
+    if (responses) responses->resize(cap);
+    if (levels) levels->resize(cap);
+    int count = 0;
+    orbx::detail::check(c,
+                        orbx_detect_and_compute(c, image.data, image.width, image.height, image.stride,
+                                                orbx::detail::kp(keypoints), orientations.data(),
+                                                orbx::detail::ds(descriptors), responses ? responses->data() : nullptr,
+                                                levels ? levels->data() : nullptr, nullptr, cap, &count),
+                        "ORB::detectAndCompute");
+    keypoints.resize(count);
+    orientations.resize(count);
+    descriptors.resize(count);
+    if (responses) responses->resize(count);
+    if (levels) levels->resize(count);
+  }
+  const orbx_params& params() const { return ctx_->params(); }
+
+ private:
+  static std::shared_ptr<orbx::detail::Ctx> make(int nfeatures, float sf, int nlevels) {
+    orbx_params p = orbx::detail::gpu_defaults();
+    p.nfeatures = nfeatures;
+    p.scale_factor = sf;
+    p.nlevels = nlevels;
+    return std::make_shared<orbx::detail::Ctx>(p);
+  }
+  std::shared_ptr<orbx::detail::Ctx> ctx_;
+};
+
+// ---- CPU-flavour twins (include/orb_cpu.hpp): same kernels, CPU semantics ----
+
+class OrientedFASTCPU {
+ public:
+  OrientedFASTCPU(int nfeatures = 3000, int threshold = 50, int n = 9, int nms_window = 3, int patch_size = 9)
+      : nfeatures(nfeatures), threshold(threshold), n(n), nms_window(nms_window), patch_size(patch_size) {}
+  std::vector<Keypoint> detect(const orbx::Image& image) {  // orb_cpu.cpp:23-137
+    std::vector<Keypoint> keypoints;
+    Fast(image, keypoints, threshold, n, nms_window, nfeatures);
+    return keypoints;
+  }
+  std::vector<float> compute_orientations(const orbx::Image& image, const std::vector<Keypoint>& keypoints) {
+    std::vector<float> o;  // orb_cpu.cpp:139-183
+    Orientations(image, keypoints, o, patch_size);
+    return o;
+  }
+
+ private:
+  int nfeatures, threshold, n, nms_window, patch_size;
+};
+
+using RotatedBRIEFCPU = RotatedBRIEF;  // orb_cpu.cpp:185-258: identical arithmetic
+
+class ORBCPU {
+ public:
+  // orb_cpu.hpp:30; like the reference, nfeatures/scaleFactor/nlevels are
+  // accepted and ignored (orb_cpu.cpp:271-276 runs one level with the
+  // OrientedFASTCPU defaults, D16)
+  ORBCPU(int = 500, float = 1.2f, int = 8) : orb_(orbx::detail::cpu_defaults()) {}
+  void detectAndCompute(const orbx::Image& image, std::vector<Keypoint>& keypoints, std::vector<float>& orientations,
+                        std::vector<ORBDescriptor>& descriptors) {
+    orb_.detectAndCompute(image, keypoints, orientations, descriptors);
+  }
+
+ private:
+  ORB orb_;
+};
