@@ -16,6 +16,8 @@
 //    rotation, Harris) use orbx_math.h and -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "orbx_internal.h"
 #include "orbx_math.h"
 
@@ -339,6 +341,183 @@ __global__ __launch_bounds__(256) void k_fast_nms(OrbxPlan plan, OrbxTileMap tm,
     if (WRITE_SCORES) {
       const int gx = x0 + ix;
       if (gy < L.h && gx < L.w) scores_dbg[(size_t)gy * L.w + gx] = (uint16_t)s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 3b. FAST + score + NMS, second generation (same results, ~3x fewer
+//     instructions per pixel).  Differences from k_fast_nms:
+//   * the 4-point pre-test runs on aligned DWORDS of the LDS tile -- 4 pixels
+//     per lane -- with packed-16-bit min/max: ">=3 of {N,E,S,W} brighter" <=>
+//     the 2nd smallest of the four >= Ip+t, ">=3 darker" <=> the 2nd largest
+//     <= Ip-t; both come out of one 8-op min/max network (v_pk_min/max_u16),
+//     the E/W/N/S/centre byte lanes are gathered with v_perm_b32;
+//   * all index arithmetic uses compile-time divisors (template on the NMS
+//     radius R);
+//   * NMS is evaluated only for corners (they are ~1% of the pixels): each
+//     corner compares itself with its (2R+1)^2 window in the LDS score tile
+//     and sets its bit in an LDS copy of the survivor mask (ds_or), which is
+//     then stored with one 8-byte store per tile row;
+//   * 8-byte global loads for the tile.
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+
+#define F2_IMG_PITCH 80                 // bytes: x0-8 .. x0+71
+#define F2_IMG_DW (F2_IMG_PITCH / 4)    // 20
+#define F2_SC_PITCH 72                  // score tile columns: x0-4 .. x0+67
+#define F2_DCOLS (F2_SC_PITCH / 4)      // 18 dword columns per score row
+
+// pre-test of the two pixels held in the 16-bit lanes of the arguments;
+// returns bit15 / bit31 set for candidates
+__device__ __forceinline__ uint32_t pretest_pk(uint32_t ip, uint32_t a, uint32_t b, uint32_t c, uint32_t d,
+                                               uint32_t t_hi, uint32_t t_lo) {
+  const us2_t A = __builtin_bit_cast(us2_t, a), B = __builtin_bit_cast(us2_t, b);
+  const us2_t C = __builtin_bit_cast(us2_t, c), D = __builtin_bit_cast(us2_t, d);
+  const us2_t I = __builtin_bit_cast(us2_t, ip);
+  const us2_t TH = __builtin_bit_cast(us2_t, t_hi), TL = __builtin_bit_cast(us2_t, t_lo);
+  const us2_t m1 = __builtin_elementwise_min(A, B), M1 = __builtin_elementwise_max(A, B);
+  const us2_t m2 = __builtin_elementwise_min(C, D), M2 = __builtin_elementwise_max(C, D);
+  const us2_t X = __builtin_elementwise_max(m1, m2), Y = __builtin_elementwise_min(M1, M2);
+  const us2_t lo2 = __builtin_elementwise_min(X, Y), hi2 = __builtin_elementwise_max(X, Y);
+  const us2_t d1 = lo2 - (I + TH);  // >= 0 (as int16) <=> at least 3 brighter
+  const us2_t d2 = (I - TL) - hi2;  // >= 0 (as int16) <=> at least 3 darker
+  return ~(__builtin_bit_cast(uint32_t, d1) & __builtin_bit_cast(uint32_t, d2)) & 0x80008000u;
+}
+
+template <int R, bool WRITE_SCORES>
+__global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxTileMap tm, const uint8_t* __restrict__ pyr,
+                                                   OrbxFastParams fp, u64* __restrict__ mask,
+                                                   uint16_t* __restrict__ scores_dbg) {
+  constexpr int TH = ORBX_FAST_TH, TW = ORBX_FAST_TW;
+  constexpr int IMG_ROWS = TH + 6 + 2 * R;
+  constexpr int SC_ROWS = TH + 2 * R;
+  constexpr int N_ITEMS = SC_ROWS * F2_DCOLS;
+  __shared__ __attribute__((aligned(16))) uint32_t s_img32[IMG_ROWS * F2_IMG_DW];
+  __shared__ __attribute__((aligned(16))) uint16_t s_score[SC_ROWS * F2_SC_PITCH];
+  __shared__ uint16_t s_queue[SC_ROWS * F2_SC_PITCH];
+  __shared__ __attribute__((aligned(8))) uint32_t s_mask32[TH * 2];
+  __shared__ int s_qn;
+
+  int l, tx, ty;
+  decode_tile(tm, plan.nlevels, l, tx, ty);
+  const OrbxLevel& L = plan.L[l];
+  const int f = blockIdx.y;
+  const uint8_t* img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
+  const int tid = threadIdx.x;
+  const int thr = fp.threshold;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const int gy0 = y0 - 3 - R;
+
+  // phase 1: tile + halo -> LDS with aligned 8-byte loads (x0-8 is 8-byte aligned)
+  for (int i = tid; i < IMG_ROWS * (F2_IMG_DW / 2); i += 256) {
+    const int row = i / (F2_IMG_DW / 2), c = i - row * (F2_IMG_DW / 2);
+    const int gy = gy0 + row, gx = x0 - 8 + 8 * c;
+    uint2 v = make_uint2(0u, 0u);
+    if (gy >= 0 && gy < L.h && gx >= 0 && gx + 8 <= L.pitch)
+      v = *reinterpret_cast<const uint2*>(img + (size_t)gy * L.pitch + gx);
+    reinterpret_cast<uint2*>(s_img32)[i] = v;
+  }
+  for (int i = tid; i < SC_ROWS * F2_SC_PITCH / 8; i += 256)
+    reinterpret_cast<uint4*>(s_score)[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < TH * 2) s_mask32[tid] = 0u;
+  if (tid == 0) s_qn = 0;
+  __syncthreads();
+
+  // phase 2: 4-point pre-test, one dword (4 pixels) per lane (src/orb_cpu.cpp:39-58)
+  {
+    const uint32_t t_hi = (uint32_t)thr * 0x00010001u;
+    // the reference's else-if makes "darker" strict when threshold == 0
+    const uint32_t t_lo = (uint32_t)(thr == 0 ? 1 : thr) * 0x00010001u;
+    for (int i = tid; i < N_ITEMS; i += 256) {
+      const int sy = i / F2_DCOLS, dc = i - sy * F2_DCOLS;
+      const int gy = y0 - R + sy, gx = x0 - 4 + 4 * dc;
+      uint32_t m4 = 0;
+      if (gy >= 3 && gy < L.h - 3 && gx + 3 >= 3 && gx < L.w - 3) {
+        const uint32_t* p = s_img32 + (sy + 3) * F2_IMG_DW + dc + 1;
+        const uint32_t C = p[0], Lw = p[-1], Rw = p[1], Nw = p[-3 * F2_IMG_DW], Sw = p[3 * F2_IMG_DW];
+        // even pixels (0,2) and odd pixels (1,3) of the dword as 16-bit lanes
+        const uint32_t ce = __builtin_amdgcn_perm(C, C, 0x0c020c00u), co = __builtin_amdgcn_perm(C, C, 0x0c030c01u);
+        const uint32_t ne = __builtin_amdgcn_perm(Nw, Nw, 0x0c020c00u), no = __builtin_amdgcn_perm(Nw, Nw, 0x0c030c01u);
+        const uint32_t se = __builtin_amdgcn_perm(Sw, Sw, 0x0c020c00u), so = __builtin_amdgcn_perm(Sw, Sw, 0x0c030c01u);
+        // east = x+3: px0 -> C.b3, px1 -> R.b0, px2 -> R.b1, px3 -> R.b2   (perm bytes: 0-3 = 2nd arg, 4-7 = 1st)
+        const uint32_t ee = __builtin_amdgcn_perm(Rw, C, 0x0c050c03u), eo = __builtin_amdgcn_perm(Rw, C, 0x0c060c04u);
+        // west = x-3: px0 -> L.b1, px1 -> L.b2, px2 -> L.b3, px3 -> C.b0
+        const uint32_t we = __builtin_amdgcn_perm(C, Lw, 0x0c030c01u), wo = __builtin_amdgcn_perm(C, Lw, 0x0c040c02u);
+        const uint32_t re = pretest_pk(ce, ne, ee, se, we, t_hi, t_lo);
+        const uint32_t ro = pretest_pk(co, no, eo, so, wo, t_hi, t_lo);
+        const uint32_t r2 = ((re >> 15) | (ro >> 14)) & 0x00030003u;  // bit0 px0, bit1 px1, bit16 px2, bit17 px3
+        m4 = (r2 | (r2 >> 14)) & 0xfu;
+        // pixels outside [3, w-3) never become corners
+        const int lo = max(0, 3 - gx), hi = min(4, L.w - 3 - gx);
+        m4 &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+      }
+      const int pos0 = sy * F2_SC_PITCH + 4 * dc;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (m4 & (1u << k)) s_queue[atomicAdd(&s_qn, 1)] = (uint16_t)(pos0 + k);
+    }
+  }
+  __syncthreads();
+
+  // phase 3: full segment test + score on the compacted candidates (src/orb_cpu.cpp:61-101)
+  const uint8_t* s_img = reinterpret_cast<const uint8_t*>(s_img32);
+  const int nq = s_qn;
+  for (int q = tid; q < nq; q += 256) {
+    const int pos = s_queue[q];
+    const int sy = pos / F2_SC_PITCH, sx = pos - sy * F2_SC_PITCH;
+    const uint8_t* p = s_img + (sy + 3) * F2_IMG_PITCH + (sx + 4);
+    const int Ip = p[0], hi = Ip + thr, lo = Ip - thr;
+    const int ring[16] = {p[-3 * F2_IMG_PITCH],     p[-3 * F2_IMG_PITCH + 1], p[-2 * F2_IMG_PITCH + 2],
+                          p[-1 * F2_IMG_PITCH + 3], p[3],                     p[F2_IMG_PITCH + 3],
+                          p[2 * F2_IMG_PITCH + 2],  p[3 * F2_IMG_PITCH + 1],  p[3 * F2_IMG_PITCH],
+                          p[3 * F2_IMG_PITCH - 1],  p[2 * F2_IMG_PITCH - 2],  p[F2_IMG_PITCH - 3],
+                          p[-3],                    p[-F2_IMG_PITCH - 3],     p[-2 * F2_IMG_PITCH - 2],
+                          p[-3 * F2_IMG_PITCH - 1]};
+    uint32_t bm = 0, dm = 0;
+    int score = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int v = ring[k];
+      bm |= (uint32_t)(v >= hi) << k;
+      dm |= (uint32_t)(v <= lo) << k;
+      score += abs(Ip - v);
+    }
+    if (has_run16(bm, fp.n) || has_run16(dm, fp.n)) s_score[pos] = (uint16_t)score;
+  }
+  __syncthreads();
+
+  // phase 4: NMS, corners only (ties survive, src/orb_cpu.cpp:110-133); survivors
+  // of the tile interior set their bit in the LDS mask
+  for (int q = tid; q < nq; q += 256) {
+    const int pos = s_queue[q];
+    const int s = s_score[pos];
+    if (s > 0) {
+      const int sy = pos / F2_SC_PITCH, sx = pos - sy * F2_SC_PITCH;
+      const int iy = sy - R, ix = sx - 4;
+      if (iy >= 0 && iy < TH && ix >= 0 && ix < TW) {
+        bool keep = true;
+#pragma unroll
+        for (int dy = -R; dy <= R; dy++)
+#pragma unroll
+          for (int dx = -R; dx <= R; dx++) keep = keep && !(s_score[pos + dy * F2_SC_PITCH + dx] > s);
+        if (keep) atomicOr(&s_mask32[iy * 2 + (ix >> 5)], 1u << (ix & 31));
+      }
+    }
+  }
+  __syncthreads();
+
+  // phase 5: one 8-byte store per tile row
+  if (tid < TH) {
+    const int gy = y0 + tid;
+    if (gy < L.h)
+      mask[(size_t)f * plan.mask_words + L.mask_off + (size_t)gy * L.mask_wpr + tx] =
+          reinterpret_cast<const u64*>(s_mask32)[tid];
+  }
+  if (WRITE_SCORES) {
+    for (int i = tid; i < TH * TW; i += 256) {
+      const int iy = i / TW, ix = i - iy * TW;
+      const int gy = y0 + iy, gx = x0 + ix;
+      if (gy < L.h && gx < L.w) scores_dbg[(size_t)gy * L.w + gx] = s_score[(iy + R) * F2_SC_PITCH + ix + 4];
     }
   }
 }
@@ -784,14 +963,44 @@ hipError_t orbx_launch_blur(hipStream_t s, const OrbxPlan& plan, const OrbxTileM
   return ORBX_LAUNCH_CHECK();
 }
 
+template <int R>
+static void launch_fast2(dim3 grid, hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, const uint8_t* d_pyr,
+                         OrbxFastParams fp, unsigned long long* d_mask, uint16_t* d_scores_dbg) {
+  if (d_scores_dbg)
+    hipLaunchKernelGGL((k_fast_nms2<R, true>), grid, dim3(256), 0, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+  else
+    hipLaunchKernelGGL((k_fast_nms2<R, false>), grid, dim3(256), 0, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+}
+
 hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
                                 const uint8_t* d_pyr, OrbxFastParams fp, unsigned long long* d_mask,
                                 uint16_t* d_scores_dbg) {
   dim3 grid(tm.begin[plan.nlevels], n_frames);
-  if (d_scores_dbg)
-    hipLaunchKernelGGL(k_fast_nms<true>, grid, dim3(256), 0, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
-  else
-    hipLaunchKernelGGL(k_fast_nms<false>, grid, dim3(256), 0, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+  static const int impl = [] {
+    const char* e = getenv("ORBX_FAST_IMPL");  // 1 = first-generation kernel (kept for A/B timing)
+    return e ? atoi(e) : 2;
+  }();
+  if (impl == 1) {
+    if (d_scores_dbg)
+      hipLaunchKernelGGL(k_fast_nms<true>, grid, dim3(256), 0, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+    else
+      hipLaunchKernelGGL(k_fast_nms<false>, grid, dim3(256), 0, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+    return ORBX_LAUNCH_CHECK();
+  }
+  switch (fp.nms_radius) {
+    case 0:
+      launch_fast2<0>(grid, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+      break;
+    case 1:
+      launch_fast2<1>(grid, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+      break;
+    case 2:
+      launch_fast2<2>(grid, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+      break;
+    default:
+      launch_fast2<3>(grid, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+      break;
+  }
   return ORBX_LAUNCH_CHECK();
 }
 
