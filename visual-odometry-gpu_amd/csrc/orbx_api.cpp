@@ -10,16 +10,13 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "orbx_internal.h"
-
-hipError_t orbx_launch_harris_flat(hipStream_t s, const uint8_t* d_img, int w, int h, int pitch,
-                                   const orbx_keypoint* d_kps, int nkp, const float* d_gauss, int K, float kk,
-                                   float* d_resp);
 
 namespace {
 
@@ -70,7 +67,7 @@ struct orbx_ctx {
   // geometry for the current frame size, and for the largest size (capacity)
   OrbxPlan plan{};
   OrbxPlan plan_max{};
-  OrbxTileMap tm_pyr{}, tm_blur{}, tm_fast{};
+  OrbxTileMap tm_pyr{}, tm_blur{}, tm_blur2{}, tm_fast{};
   std::vector<OrbxResizeTap> h_taps;
   int plan_w = 0, plan_h = 0;
 
@@ -205,9 +202,11 @@ int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string
     cand_off += L.cap;
     out_cap += quota;
     L.scale = level_scale(p.scale_factor, l);
+    // x table first (padded to a multiple of 4 entries = 32 bytes so that a thread's
+    // four taps are two aligned 16-byte loads), then the y table
     L.xtab_off = xt;
-    L.ytab_off = xt + (l == 0 ? 0 : L.w);
-    xt += (l == 0 ? 0 : L.w + L.h);
+    L.ytab_off = xt + (l == 0 ? 0 : align_up(L.w, 4));
+    xt += (l == 0 ? 0 : align_up(L.w, 4) + align_up(L.h, 4));
     if (img_off > 0x7fffffffull) {
       *why = "pyramid frame exceeds 2 GiB";
       return ORBX_ERR_UNSUPPORTED;
@@ -226,7 +225,7 @@ int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string
 // OpenCV is not part of this image: PARITY UNPINNED (DESIGN.md "Pyramid").
 void make_taps(const OrbxPlan& plan, std::vector<OrbxResizeTap>* taps) {
   size_t total = 0;
-  for (int l = 1; l < plan.nlevels; l++) total += (size_t)plan.L[l].w + plan.L[l].h;
+  for (int l = 1; l < plan.nlevels; l++) total += (size_t)align_up(plan.L[l].w, 4) + align_up(plan.L[l].h, 4);
   taps->assign(total ? total : 1, OrbxResizeTap{0, 0, 0});
   for (int l = 1; l < plan.nlevels; l++) {
     const OrbxLevel& L = plan.L[l];
@@ -247,6 +246,13 @@ void make_taps(const OrbxPlan& plan, std::vector<OrbxResizeTap>* taps) {
       t.ofs = sx;
       t.c0 = (int16_t)std::lrintf((1.f - fx) * 2048.f);
       t.c1 = (int16_t)std::lrintf(fx * 2048.f);
+      if (sx == plan.w0 - 1) {
+        // src[w0-1]*c0 (+ src[w0-1]*0) == src[w0-2]*0 + src[w0-1]*c0: same sum, but the
+        // kernel may now always fetch the pair (ofs, ofs+1) with one 16-bit load
+        t.ofs = plan.w0 - 2;
+        t.c1 = t.c0;
+        t.c0 = 0;
+      }
     }
     for (int dy = 0; dy < L.h; dy++) {
       float fy = (float)((dy + 0.5) * scale_y - 0.5);
@@ -316,13 +322,34 @@ int set_plan(orbx_ctx* c, int w, int h) {
   c->plan = plan;
   make_tilemap(plan, ORBX_PYR_TW, ORBX_PYR_TH, true, &c->tm_pyr);
   make_tilemap(plan, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &c->tm_blur);
+  make_tilemap(plan, ORBX_BLUR2_TW, 4 * orbx_blur2_rows_per_wave(), true, &c->tm_blur2);
   make_tilemap(plan, ORBX_FAST_TW, ORBX_FAST_TH, false, &c->tm_fast);
   c->plan_w = w;
   c->plan_h = h;
   return ORBX_OK;
 }
 
+int fast_ablate() {  // timing diagnostics only: results are wrong when non-zero
+  static const int v = [] {
+    const char* e = getenv("ORBX_FAST_ABLATE");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 bool blur_enabled(const orbx_ctx* c) { return c->p.blur_levels != ORBX_BLUR_NONE; }
+
+// separable kind -> register-streaming kernel; /273 kind -> LDS tile kernel.
+// ORBX_BLUR_IMPL=1 forces the first-generation kernel (A/B timing).
+hipError_t launch_blur_auto(hipStream_t s, const OrbxPlan& P, const OrbxTileMap& tm1, const OrbxTileMap& tm2,
+                            int n, const uint8_t* src, uint8_t* dst, int first_level, int kind) {
+  static const int impl = [] {
+    const char* e = getenv("ORBX_BLUR_IMPL");
+    return e ? atoi(e) : 2;
+  }();
+  if (kind == ORBX_BLUR_SEP16 && impl != 1) return orbx_launch_blur2(s, P, tm2, n, src, dst, first_level);
+  return orbx_launch_blur(s, P, tm1, n, src, dst, first_level, kind);
+}
 const uint8_t* final_pyr(const orbx_ctx* c) { return blur_enabled(c) ? c->d_pyr_blur : c->d_pyr; }
 
 // the whole path for n frames already on the device
@@ -337,10 +364,10 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   HIPCHK(c, orbx_launch_pyramid(s, P, c->tm_pyr, n, d_frames, row_stride, frame_stride, c->d_taps, c->d_pyr));
   if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
   if (blur_enabled(c))
-    HIPCHK(c, orbx_launch_blur(s, P, c->tm_blur, n, c->d_pyr, c->d_pyr_blur,
+    HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->tm_blur2, n, c->d_pyr, c->d_pyr_blur,
                                c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
   if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
-  OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2};
+  OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2, fast_ablate()};
   HIPCHK(c, orbx_launch_fast_nms(s, P, c->tm_fast, n, final_pyr(c), fp, c->d_mask, nullptr));
   if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
   HIPCHK(c, orbx_launch_compact(s, P, n, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total));
@@ -549,7 +576,7 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
   CREATE_CHK(hipMalloc((void**)&c->d_resp, B * (size_t)std::max(M.cand_total, 1) * sizeof(float)));
   {
     size_t taps = 1;
-    for (int l = 1; l < M.nlevels; l++) taps += (size_t)M.L[l].w + M.L[l].h;
+    for (int l = 1; l < M.nlevels; l++) taps += (size_t)align_up(M.L[l].w, 4) + align_up(M.L[l].h, 4);
     // level sizes of smaller frames never exceed those of the largest frame
     c->taps_capacity = taps + 16;
     CREATE_CHK(hipMalloc((void**)&c->d_taps, c->taps_capacity * sizeof(OrbxResizeTap)));
@@ -717,14 +744,14 @@ int orbx_bench_stage(orbx_ctx* c, int n_frames, int stage, int reps, float* avg_
   if (n_frames < 1 || n_frames > c->last_n || reps < 1) return fail(c, ORBX_ERR_INVALID_ARG, "n_frames/reps");
   const OrbxPlan& P = c->plan;
   hipStream_t s = c->stream;
-  OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2};
+  OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2, fast_ablate()};
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipEventRecord(c->ev[0], s));
   for (int i = 0; i < reps; i++) {
     switch (stage) {
       case ORBX_STAGE_BLUR:
         if (!blur_enabled(c)) return fail(c, ORBX_ERR_INVALID_ARG, "blur is disabled in this context");
-        HIPCHK(c, orbx_launch_blur(s, P, c->tm_blur, n_frames, c->d_pyr, c->d_pyr_blur,
+        HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->tm_blur2, n_frames, c->d_pyr, c->d_pyr_blur,
                                    c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
         break;
       case ORBX_STAGE_FAST:
@@ -762,7 +789,7 @@ int orbx_fast_score(orbx_ctx* c, const uint8_t* image, int width, int height, in
   const size_t npx = (size_t)width * height;
   if ((st = ensure(c, c->s_u16, npx * 2)) != ORBX_OK) return st;
   if ((st = ensure(c, c->s_mask, (size_t)P.mask_words * 8)) != ORBX_OK) return st;
-  OrbxFastParams fp{threshold, n, 0};
+  OrbxFastParams fp{threshold, n, 0, 0};
   HIPCHK(c, orbx_launch_fast_nms(c->stream, P, tm, 1, (const uint8_t*)c->s_img_a.p, fp,
                                  (unsigned long long*)c->s_mask.p, (uint16_t*)c->s_u16.p));
   std::vector<uint16_t> h(npx);
@@ -804,7 +831,7 @@ int orbx_fast(orbx_ctx* c, const uint8_t* image, int width, int height, int stri
   OrbxTileMap tm;
   make_tilemap(P, ORBX_FAST_TW, ORBX_FAST_TH, false, &tm);
   if ((st = ensure(c, c->s_mask, (size_t)P.mask_words * 8)) != ORBX_OK) return st;
-  OrbxFastParams fp{threshold, n, nms_window / 2};
+  OrbxFastParams fp{threshold, n, nms_window / 2, 0};
   HIPCHK(c, orbx_launch_fast_nms(c->stream, P, tm, 1, (const uint8_t*)c->s_img_a.p, fp,
                                  (unsigned long long*)c->s_mask.p, nullptr));
   return compact_and_fetch(c, P, nfeatures, keypoints, count, total);
@@ -916,9 +943,10 @@ static int blur_stage(orbx_ctx* c, const uint8_t* image, int width, int height, 
   if (st != ORBX_OK) return st;
   OrbxPlan P = flat_plan(width, height, 0);
   if ((st = ensure(c, c->s_img_b, (size_t)P.frame_bytes + 256)) != ORBX_OK) return st;
-  OrbxTileMap tm;
+  OrbxTileMap tm, tm2;
   make_tilemap(P, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &tm);
-  HIPCHK(c, orbx_launch_blur(c->stream, P, tm, 1, (const uint8_t*)c->s_img_a.p, (uint8_t*)c->s_img_b.p, 0, kind));
+  make_tilemap(P, ORBX_BLUR2_TW, 4 * orbx_blur2_rows_per_wave(), true, &tm2);
+  HIPCHK(c, launch_blur_auto(c->stream, P, tm, tm2, 1, (const uint8_t*)c->s_img_a.p, (uint8_t*)c->s_img_b.p, 0, kind));
   HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, c->s_img_b.p, pitch, width, height, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return ORBX_OK;
@@ -994,7 +1022,7 @@ int orbx_build_pyramid_level(orbx_ctx* c, const uint8_t* image, int width, int h
   HIPCHK(c, orbx_launch_pyramid(c->stream, P, c->tm_pyr, 1, c->d_in, width, (size_t)width * height, c->d_taps,
                                 c->d_pyr));
   if (blur_enabled(c))
-    HIPCHK(c, orbx_launch_blur(c->stream, P, c->tm_blur, 1, c->d_pyr, c->d_pyr_blur,
+    HIPCHK(c, launch_blur_auto(c->stream, P, c->tm_blur, c->tm_blur2, 1, c->d_pyr, c->d_pyr_blur,
                                c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
   const OrbxLevel& L = P.L[level];
   HIPCHK(c, hipMemcpy2DAsync(dst, L.w, final_pyr(c) + L.img_off, L.pitch, L.w, L.h, hipMemcpyDeviceToHost,

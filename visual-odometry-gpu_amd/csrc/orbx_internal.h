@@ -52,14 +52,19 @@ struct OrbxResizeTap {
 
 struct OrbxFastParams {
   int32_t threshold, n, nms_radius;
+  int32_t ablate;  // timing diagnostics only (ORBX_FAST_ABLATE); 0 in production
 };
 
 // tile geometry of the FAST/NMS kernel
 #define ORBX_FAST_TW 64
-#define ORBX_FAST_TH 32
+#define ORBX_FAST_TH 64
 // tile geometry of the blur kernel
 #define ORBX_BLUR_TW 64
 #define ORBX_BLUR_TH 16
+// tile geometry of the register-streaming separable blur (k_blur2): 4 waves x 16 rows
+#define ORBX_BLUR2_TW 248
+#define ORBX_BLUR2_TH 64
+int orbx_blur2_rows_per_wave();  // 16 or 32; tile height of k_blur2 = 4x this
 // tile geometry of the pyramid kernel (each thread: 4 px)
 #define ORBX_PYR_TW 256
 #define ORBX_PYR_TH 4
@@ -73,12 +78,17 @@ hipError_t orbx_launch_pyramid(hipStream_t s, const OrbxPlan& plan, const OrbxTi
                                const OrbxResizeTap* d_taps, uint8_t* d_pyr);
 hipError_t orbx_launch_blur(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
                             const uint8_t* d_src, uint8_t* d_dst, int first_level, int kind);
+hipError_t orbx_launch_blur2(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
+                             const uint8_t* d_src, uint8_t* d_dst, int first_level);
 hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
                                 const uint8_t* d_pyr, OrbxFastParams fp, unsigned long long* d_mask,
                                 uint16_t* d_scores_dbg);
 hipError_t orbx_launch_compact(hipStream_t s, const OrbxPlan& plan, int n_frames,
                                const unsigned long long* d_mask, orbx_keypoint* d_cand, int32_t* d_cand_count,
                                int32_t* d_cand_total);
+hipError_t orbx_launch_harris_flat(hipStream_t s, const uint8_t* d_img, int w, int h, int pitch,
+                                   const orbx_keypoint* d_kps, int nkp, const float* d_gauss, int K, float kk,
+                                   float* d_resp);
 hipError_t orbx_launch_harris(hipStream_t s, const OrbxPlan& plan, int n_frames, const uint8_t* d_pyr,
                               const orbx_keypoint* d_cand, const int32_t* d_cand_count, const float* d_gauss,
                               int window, float k, float* d_resp);

@@ -22,13 +22,16 @@
 #include "orbx_math.h"
 
 typedef unsigned long long u64;
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 
-__constant__ int8_t c_pattern[1024] = {
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 #include "pattern_31.inc"
 };
 
 // ---------------------------------------------------------------------------
 // helpers
+
+typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
@@ -92,14 +95,22 @@ __global__ __launch_bounds__(256) void k_pyramid(OrbxPlan plan, OrbxTileMap tm, 
     const uint8_t* S0 = src + (size_t)sy0 * in_stride;
     const uint8_t* S1 = src + (size_t)sy1 * in_stride;
     const int b0 = ty_.c0, b1 = ty_.c1;
+    // the four x taps of this thread: 32 contiguous, 32-byte aligned bytes of the
+    // table (x tables are padded to a multiple of 4 entries) -> two 16-byte loads
+    const uint4* tp = reinterpret_cast<const uint4*>(taps + L.xtab_off + x);
+    const uint4 t01 = tp[0], t23 = tp[1];
+    const uint32_t ofs[4] = {t01.x, t01.z, t23.x, t23.z};
+    const uint32_t cc[4] = {t01.y, t01.w, t23.y, t23.w};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int xx = x + k;
-      if (xx < L.w) {
-        const OrbxResizeTap t = taps[L.xtab_off + xx];
-        const int sx = t.ofs, sx1 = min(sx + 1, plan.w0 - 1);
-        const int r0 = S0[sx] * t.c0 + S0[sx1] * t.c1;
-        const int r1 = S1[sx] * t.c0 + S1[sx1] * t.c1;
+      if (x + k < L.w) {
+        // ofs <= w0-2 always (host table), so one unaligned 16-bit load fetches
+        // src[ofs] (low byte) and src[ofs+1] (high byte)
+        const uint32_t p0 = *reinterpret_cast<const u16_unaligned*>(S0 + ofs[k]);
+        const uint32_t p1 = *reinterpret_cast<const u16_unaligned*>(S1 + ofs[k]);
+        const int c0 = (int)(cc[k] & 0xffffu), c1 = (int)(cc[k] >> 16);
+        const int r0 = (int)(p0 & 0xffu) * c0 + (int)(p0 >> 8) * c1;
+        const int r1 = (int)(p1 & 0xffu) * c0 + (int)(p1 >> 8) * c1;
         const uint32_t v = (uint32_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
         out |= v << (8 * k);
       }
@@ -205,6 +216,137 @@ __global__ __launch_bounds__(256) void k_blur(OrbxPlan plan, OrbxTileMap tm, con
     }
   }
   if (gy < L.h && gx < L.pitch) *reinterpret_cast<uint32_t*>(out + (size_t)gy * L.pitch + gx) = packed;
+}
+
+// ---------------------------------------------------------------------------
+// 2b. separable 5x5 blur, second generation: NO LDS, NO barriers.
+//   One wavefront owns a 256-pixel-wide column strip (64 lanes x one aligned
+//   dword = 4 pixels) and walks BL2_RH+4 rows top to bottom:
+//     * each row is one coalesced 256-byte global load per wave; the left /
+//       right neighbour dwords come from the adjacent lanes with DPP
+//       wave_shr/wave_shl (lane 0 / lane 63 fetch one extra dword);
+//     * the horizontal [1 4 6 4 1] pass runs on packed 16-bit lanes
+//       (v_perm_b32 gathers the shifted byte pairs, v_pk_add/mad_u16 does two
+//       pixels per op); the five most recent H rows live in registers, so the
+//       vertical pass needs no memory at all;
+//     * rne(S/256) is (S + 127 + ((S>>8)&1)) >> 8 on packed lanes, repacked
+//       to one dword store per lane per row.
+//   REFLECT_101: rows by index; columns by patching the dword that holds the
+//   image's last pixel (and the virtual dword left of x = 0) with v_perm.
+#define BL2_TW 248   // productive pixels per wave row: lanes 1..62 (lanes 0 and 63 are halo-only)
+
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) + __builtin_bit_cast(us2_t, b)));
+}
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, unsigned short m, uint32_t c) {
+  const us2_t mm = {m, m};
+  return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) * mm + __builtin_bit_cast(us2_t, c)));
+}
+// round-half-even of S/256 on both 16-bit lanes
+__device__ __forceinline__ uint32_t pk_rne8(uint32_t S) {
+  const us2_t s = __builtin_bit_cast(us2_t, S);
+  const us2_t one = {1, 1}, c127 = {127, 127};
+  const us2_t r = (us2_t)(s + c127 + ((s >> 8) & one)) >> 8;
+  return __builtin_bit_cast(uint32_t, r);
+}
+
+// wave-uniform REFLECT_101 on scalars (row index)
+__device__ __forceinline__ int reflect101_s(int p, int len) {
+  p = p < 0 ? -p : p;
+  p = p >= len ? 2 * len - p - 2 : p;
+  p = p < 0 ? 0 : p;
+  return p >= len ? len - 1 : p;
+}
+
+template <int RH>
+__global__ __launch_bounds__(256) void k_blur2(OrbxPlan plan, OrbxTileMap tm, const uint8_t* __restrict__ src,
+                                               uint8_t* __restrict__ dst, int first_level) {
+  int l, tx, ty;
+  decode_tile(tm, plan.nlevels, l, tx, ty);
+  const OrbxLevel& L = plan.L[l];
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: row math runs on the SALU
+  const int x = tx * BL2_TW - 4 + lane * 4;  // lane 0 holds the dword left of the strip
+  const int ya = ty * (4 * RH) + wave * RH;
+  if (ya >= L.h) return;  // whole wave
+  const int pitch = L.pitch, h = L.h;
+  // Buffer descriptors over the level image: the (scalar) row base goes in the
+  // scalar offset, the lane's x in the vector offset; lanes whose x is outside
+  // [0, pitch) use an out-of-range vector offset, so the hardware range check
+  // zero-fills their loads and drops their stores -- no exec-mask juggling, no
+  // 64-bit per-lane address arithmetic.
+  const size_t level_off = (size_t)f * plan.frame_bytes + L.img_off;
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src) + level_off, 0, pitch * h, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(dst + level_off, 0, pitch * h, 0x00020000);
+  const uint32_t voff_ld = (x >= 0 && x < pitch) ? (uint32_t)x : 0xffffffffu;
+  const uint32_t voff_st = (lane >= 1 && lane <= 62 && x < pitch) ? (uint32_t)x : 0xffffffffu;
+
+  if (l < first_level) {  // pass-through copy
+#pragma unroll 4
+    for (int i = 0; i < RH; i++) {
+      const int y = ya + i;
+      if (y < h) {
+        const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(rin, voff_st, y * pitch, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(v, rout, voff_st, y * pitch, 0);
+      }
+    }
+    return;
+  }
+
+  // every row of the strip is requested before the first one is used
+  uint32_t Craw[RH + 4];
+#pragma unroll
+  for (int i = 0; i < RH + 4; i++)
+    Craw[i] = __builtin_amdgcn_raw_buffer_load_b32(rin, voff_ld, reflect101_s(ya - 2 + i, h) * pitch, 0);
+
+  // column REFLECT_101 as per-lane v_perm selectors (identity except in the lane
+  // holding x = 0 and the lane holding the image's last pixel)
+  const int e4 = (L.w - 1) & ~3;    // x of the dword holding the last pixel
+  const int rbyte = (L.w - 1) & 3;  // its position inside that dword
+  const bool edge = (x == e4);
+  // Lw = perm(C, Ldpp, selL): bytes 0-3 = Ldpp, 4-7 = C.   x=-1 <- x=1, x=-2 <- x=2
+  const uint32_t selL = x == 0 ? 0x05060c0cu : 0x03020100u;
+  // C' = perm(C, Lw, selC): bytes 0-3 = Lw, 4-7 = C
+  const uint32_t selC_e = rbyte == 3 ? 0x07060504u : rbyte == 2 ? 0x05060504u : rbyte == 1 ? 0x03040504u : 0x07020304u;
+  const uint32_t selC = edge ? selC_e : 0x07060504u;
+  // Rw = perm(C0, Rdpp, selR): bytes 0-3 = Rdpp, 4-7 = C0 (the unpatched edge dword)
+  const uint32_t selR_e = rbyte == 3 ? 0x0c0c0506u : rbyte == 2 ? 0x0c0c0c04u : 0x0c0c0c0cu;
+  const uint32_t selR = edge ? selR_e : 0x03020100u;
+  // output bytes at x >= w are written as zero (padding stays zero)
+  const int nvalid = L.w - x;
+  const uint32_t vmask = nvalid >= 4 ? 0xffffffffu : nvalid <= 0 ? 0u : ((1u << (8 * nvalid)) - 1u);
+
+  uint32_t he[5], ho[5];
+#pragma unroll
+  for (int i = 0; i < RH + 4; i++) {
+    const uint32_t C0 = Craw[i];
+    const uint32_t Ld = __builtin_amdgcn_update_dpp(C0, C0, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+    const uint32_t Lw = __builtin_amdgcn_perm(C0, Ld, selL);
+    const uint32_t C = __builtin_amdgcn_perm(C0, Lw, selC);
+    const uint32_t Rd = __builtin_amdgcn_update_dpp(C, C, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+    const uint32_t Rw = __builtin_amdgcn_perm(C0, Rd, selR);
+
+    // byte pairs (16-bit lanes): perm bytes 0-3 = 2nd argument, 4-7 = 1st
+    const uint32_t A = __builtin_amdgcn_perm(C, Lw, 0x0c040c02u);   // (L.b2, C.b0)
+    const uint32_t B = __builtin_amdgcn_perm(C, Lw, 0x0c050c03u);   // (L.b3, C.b1)
+    const uint32_t Cc = __builtin_amdgcn_perm(C, C, 0x0c020c00u);   // (C.b0, C.b2)
+    const uint32_t D = __builtin_amdgcn_perm(C, C, 0x0c030c01u);    // (C.b1, C.b3)
+    const uint32_t E = __builtin_amdgcn_perm(Rw, C, 0x0c040c02u);   // (C.b2, R.b0)
+    const uint32_t F = __builtin_amdgcn_perm(Rw, C, 0x0c050c03u);   // (C.b3, R.b1)
+    he[i % 5] = pk_mad(pk_add(B, D), 4, pk_mad(Cc, 6, pk_add(A, E)));   // pixels 0,2
+    ho[i % 5] = pk_mad(pk_add(Cc, E), 4, pk_mad(D, 6, pk_add(B, F)));   // pixels 1,3
+    if (i >= 4) {
+      const int y = ya + i - 4;
+      // window rows y-2..y+2 are slots (i-4)%5 .. i%5
+      const uint32_t ve = pk_rne8(pk_mad(pk_add(he[(i - 3) % 5], he[(i - 1) % 5]), 4,
+                                         pk_mad(he[(i - 2) % 5], 6, pk_add(he[(i - 4) % 5], he[i % 5]))));
+      const uint32_t vo = pk_rne8(pk_mad(pk_add(ho[(i - 3) % 5], ho[(i - 1) % 5]), 4,
+                                         pk_mad(ho[(i - 2) % 5], 6, pk_add(ho[(i - 4) % 5], ho[i % 5]))));
+      if (y < h) __builtin_amdgcn_raw_buffer_store_b32((ve | (vo << 8)) & vmask, rout, voff_st, y * pitch, 0);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -360,7 +502,6 @@ __global__ __launch_bounds__(256) void k_fast_nms(OrbxPlan plan, OrbxTileMap tm,
 //     and sets its bit in an LDS copy of the survivor mask (ds_or), which is
 //     then stored with one 8-byte store per tile row;
 //   * 8-byte global loads for the tile.
-typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 
 #define F2_IMG_PITCH 80                 // bytes: x0-8 .. x0+71
 #define F2_IMG_DW (F2_IMG_PITCH / 4)    // 20
@@ -424,7 +565,7 @@ __global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxTileMap tm
   __syncthreads();
 
   // phase 2: 4-point pre-test, one dword (4 pixels) per lane (src/orb_cpu.cpp:39-58)
-  {
+  if (!(fp.ablate & 2)) {
     const uint32_t t_hi = (uint32_t)thr * 0x00010001u;
     // the reference's else-if makes "darker" strict when threshold == 0
     const uint32_t t_lo = (uint32_t)(thr == 0 ? 1 : thr) * 0x00010001u;
@@ -451,6 +592,7 @@ __global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxTileMap tm
         const int lo = max(0, 3 - gx), hi = min(4, L.w - 3 - gx);
         m4 &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
       }
+      if (fp.ablate & 1) m4 = 0;  // diagnostics: no candidates -> phases 3/4 are empty
       const int pos0 = sy * F2_SC_PITCH + 4 * dc;
 #pragma unroll
       for (int k = 0; k < 4; k++)
@@ -488,7 +630,7 @@ __global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxTileMap tm
 
   // phase 4: NMS, corners only (ties survive, src/orb_cpu.cpp:110-133); survivors
   // of the tile interior set their bit in the LDS mask
-  for (int q = tid; q < nq; q += 256) {
+  for (int q = tid; q < ((fp.ablate & 4) ? 0 : nq); q += 256) {
     const int pos = s_queue[q];
     const int s = s_score[pos];
     if (s > 0) {
@@ -722,6 +864,15 @@ __global__ __launch_bounds__(256) void k_select_flat(const float* __restrict__ r
 #define DESC_R 20
 #define DESC_ROWS (2 * DESC_R + 1)  // 41
 #define DESC_PITCH 48               // bytes per LDS patch row (12 dwords)
+#define DESC_HP 40                  // u16 entries per row of the box-sum tables
+#define DESC_BROWS (DESC_ROWS - 4)  // 37 rows of 5x5 box sums
+
+// per-wavefront LDS working set
+struct DescLds {
+  uint32_t patch[DESC_ROWS * DESC_PITCH / 4];  // 41 x 48 u8
+  uint16_t hs[DESC_ROWS * DESC_HP];            // horizontal 5-sums: hs[r][j] = sum patch[r][j..j+4]
+  uint16_t box[DESC_BROWS * DESC_HP];          // 5x5 sums: box[r][j] = sum hs[r..r+4][j]
+};
 
 struct DescJob {
   const uint8_t* img;
@@ -730,11 +881,17 @@ struct DescJob {
   bool valid;
 };
 
-__device__ __forceinline__ void describe_wave(const DescJob& jb, uint8_t* s_patch, int patch_size,
+// The 512 box sums a descriptor needs are looked up in a per-keypoint table of
+// ALL 5x5 box sums of the 41x41 neighbourhood, built with two separable passes
+// of wide, conflict-free LDS accesses (2 dword reads -> 4 sums -> one 8-byte
+// write; 5 8-byte reads -> one 8-byte write) instead of 25 scattered byte reads
+// per sample.  Sums are exact integers (<= 6375), identical to what the
+// reference derives from its integral image (src/orb_cpu.cpp:190-201).
+__device__ __forceinline__ void describe_wave(const DescJob& jb, DescLds& lds, int patch_size,
                                               bool use_given_angle, float given_angle, bool do_brief,
                                               float& angle_out, u64 desc_out[4]) {
   const int lane = lane_id();
-  uint32_t* s32 = reinterpret_cast<uint32_t*>(s_patch);
+  const uint8_t* s_patch = reinterpret_cast<const uint8_t*>(lds.patch);
   const int px0 = jb.x - DESC_R, py0 = jb.y - DESC_R;
   const int ax0 = px0 & ~3;  // floor to a multiple of 4 (two's complement)
   const int off = px0 - ax0;
@@ -745,7 +902,7 @@ __device__ __forceinline__ void describe_wave(const DescJob& jb, uint8_t* s_patc
       uint32_t v = 0;
       if (gy >= 0 && gy < jb.h && gx >= 0 && gx + 4 <= jb.pitch)
         v = *reinterpret_cast<const uint32_t*>(jb.img + (size_t)gy * jb.pitch + gx);
-      s32[i] = v;
+      lds.patch[i] = v;
     }
   }
   __syncthreads();
@@ -757,13 +914,20 @@ __device__ __forceinline__ void describe_wave(const DescJob& jb, uint8_t* s_patc
       const int pr = patch_size / 2, P = 2 * pr + 1;
       // full patch must lie inside the image, else 0 (src/orb_cpu.cpp:152-156)
       if (!(jb.x - pr < 0 || jb.x + pr >= jb.w || jb.y - pr < 0 || jb.y + pr >= jb.h)) {
-        int m10 = 0, m01 = 0;
-        for (int i = lane; i < P * P; i += 64) {
-          const int rr = i / P, cc = i - rr * P;
-          const int I = s_patch[(rr - pr + DESC_R) * DESC_PITCH + (cc - pr + DESC_R + off)];
-          m10 += (cc - pr) * I;
-          m01 += (rr - pr) * I;
+        // lanes = patch columns (two row groups when the patch is <= 32 wide),
+        // rows in the loop: no per-pixel division, one LDS byte read per step
+        const int grp_shift = P <= 32 ? 5 : 6;
+        const int col = lane & ((1 << grp_shift) - 1), grp = lane >> grp_shift, ngrp = 64 >> grp_shift;
+        int colsum = 0, m01 = 0;
+        if (col < P) {
+          const uint8_t* pc = s_patch + (DESC_R - pr) * DESC_PITCH + (col - pr + DESC_R + off);
+          for (int rr = grp; rr < P; rr += ngrp) {
+            const int I = pc[rr * DESC_PITCH];
+            colsum += I;
+            m01 += (rr - pr) * I;
+          }
         }
+        int m10 = (col - pr) * colsum;
         m10 = wave_sum(m10);
         m01 = wave_sum(m01);
         // the reference accumulates in float; every partial sum is an integer
@@ -774,14 +938,46 @@ __device__ __forceinline__ void describe_wave(const DescJob& jb, uint8_t* s_patc
   }
   angle_out = angle;
   if (!do_brief) return;
+
+  // pass 1: horizontal 5-sums, 4 per item (row r, dword group g)
+  if (jb.valid) {
+    for (int i = lane; i < DESC_ROWS * 10; i += 64) {
+      const int r = i / 10, g = i - r * 10;
+      const uint32_t d0 = lds.patch[r * (DESC_PITCH / 4) + g], d1 = lds.patch[r * (DESC_PITCH / 4) + g + 1];
+      const uint32_t b0 = d0 & 0xff, b1 = (d0 >> 8) & 0xff, b2 = (d0 >> 16) & 0xff, b3 = d0 >> 24;
+      const uint32_t b4 = d1 & 0xff, b5 = (d1 >> 8) & 0xff, b6 = (d1 >> 16) & 0xff, b7 = d1 >> 24;
+      const uint32_t s0 = b0 + b1 + b2 + b3 + b4;
+      const uint32_t s1 = s0 - b0 + b5, s2 = s1 - b1 + b6, s3 = s2 - b2 + b7;
+      *reinterpret_cast<uint2*>(&lds.hs[r * DESC_HP + 4 * g]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+    }
+  }
+  __syncthreads();
+  // pass 2: vertical 5-sums of the horizontal sums
+  if (jb.valid) {
+    for (int i = lane; i < DESC_BROWS * 10; i += 64) {
+      const int r = i / 10, g = i - r * 10;
+      const uint2* hp = reinterpret_cast<const uint2*>(&lds.hs[r * DESC_HP + 4 * g]);
+      uint2 acc = hp[0];
+#pragma unroll
+      for (int k = 1; k < 5; k++) {
+        const uint2 v = hp[k * (DESC_HP / 4)];
+        acc.x = pk_add(acc.x, v.x);
+        acc.y = pk_add(acc.y, v.y);
+      }
+      *reinterpret_cast<uint2*>(&lds.box[r * DESC_HP + 4 * g]) = acc;
+    }
+  }
+  __syncthreads();
+
   const float c = orbx_cosf(angle), s = orbx_sinf(angle);
 #pragma unroll 1
   for (int k = 0; k < 4; k++) {
     bool bit = false;
     if (jb.valid) {
       const int i = k * 64 + lane;
-      const float x1 = (float)c_pattern[i * 4], y1 = (float)c_pattern[i * 4 + 1];
-      const float x2 = (float)c_pattern[i * 4 + 2], y2 = (float)c_pattern[i * 4 + 3];
+      const int32_t pk = reinterpret_cast<const int32_t*>(c_pattern)[i];
+      const float x1 = (float)(int8_t)(pk & 0xff), y1 = (float)(int8_t)((pk >> 8) & 0xff);
+      const float x2 = (float)(int8_t)((pk >> 16) & 0xff), y2 = (float)(int8_t)((pk >> 24) & 0xff);
       // lround(c*x - s*y), lround(s*x + c*y): separate IEEE mul / add-sub,
       // round half away from zero (src/orb_cpu.cpp:228-232)
       int dx1 = orbx_lroundf(__fsub_rn(__fmul_rn(c, x1), __fmul_rn(s, y1)));
@@ -799,16 +995,8 @@ __device__ __forceinline__ void describe_wave(const DescJob& jb, uint8_t* s_patc
         dy1 = min(max(dy1, -18), 18);
         dx2 = min(max(dx2, -18), 18);
         dy2 = min(max(dy2, -18), 18);
-        const uint8_t* p1 = s_patch + (dy1 + DESC_R - 2) * DESC_PITCH + (dx1 + DESC_R + off - 2);
-        const uint8_t* p2 = s_patch + (dy2 + DESC_R - 2) * DESC_PITCH + (dx2 + DESC_R + off - 2);
-        int s1 = 0, s2 = 0;
-#pragma unroll
-        for (int yy = 0; yy < 5; yy++)
-#pragma unroll
-          for (int xx = 0; xx < 5; xx++) {
-            s1 += p1[yy * DESC_PITCH + xx];
-            s2 += p2[yy * DESC_PITCH + xx];
-          }
+        const int s1 = lds.box[(dy1 + 18) * DESC_HP + dx1 + 18 + off];
+        const int s2 = lds.box[(dy2 + 18) * DESC_HP + dx2 + 18 + off];
         bit = s1 < s2;
       }
     }
@@ -823,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbxPlan plan, const uint8_t* 
                                                   orbx_keypoint* __restrict__ out_kp,
                                                   float* __restrict__ out_angle,
                                                   orbx_descriptor* __restrict__ out_desc) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][DESC_ROWS * DESC_PITCH];
+  __shared__ __attribute__((aligned(16))) DescLds s_lds[4];
   const int f = blockIdx.y, wave = threadIdx.x >> 6;
   const int slot = blockIdx.x * 4 + wave;
   const int count = out_count[f];
@@ -844,7 +1032,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbxPlan plan, const uint8_t* 
   jb.y = kp.y;
   float angle;
   u64 d[4];
-  describe_wave(jb, s_patch[wave], patch_size, false, 0.0f, true, angle, d);
+  describe_wave(jb, s_lds[wave], patch_size, false, 0.0f, true, angle, d);
   if (jb.valid && lane_id() == 0) {
     const size_t o = (size_t)f * plan.out_cap + slot;
     out_angle[o] = angle;
@@ -865,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_describe_flat(const uint8_t* __restrict
                                                        int patch_size, int use_given_angles, int do_brief,
                                                        float* __restrict__ angles,
                                                        orbx_descriptor* __restrict__ desc) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][DESC_ROWS * DESC_PITCH];
+  __shared__ __attribute__((aligned(16))) DescLds s_lds[4];
   const int wave = threadIdx.x >> 6;
   const int slot = blockIdx.x * 4 + wave;
   DescJob jb;
@@ -879,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_describe_flat(const uint8_t* __restrict
   const float given = (jb.valid && use_given_angles) ? angles[slot] : 0.0f;
   float angle;
   u64 d[4];
-  describe_wave(jb, s_patch[wave], patch_size, use_given_angles != 0, given, do_brief != 0, angle, d);
+  describe_wave(jb, s_lds[wave], patch_size, use_given_angles != 0, given, do_brief != 0, angle, d);
   if (jb.valid && lane_id() == 0) {
     if (!use_given_angles) angles[slot] = angle;
     if (do_brief) {
@@ -960,6 +1148,25 @@ hipError_t orbx_launch_blur(hipStream_t s, const OrbxPlan& plan, const OrbxTileM
                             const uint8_t* d_src, uint8_t* d_dst, int first_level, int kind) {
   dim3 grid(tm.begin[plan.nlevels], n_frames);
   hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, s, plan, tm, d_src, d_dst, first_level, kind);
+  return ORBX_LAUNCH_CHECK();
+}
+
+int orbx_blur2_rows_per_wave() {
+  static const int v = [] {
+    const char* e = getenv("ORBX_BLUR2_RH");  // 16 (default) or 32 rows per wavefront
+    return (e && atoi(e) == 32) ? 32 : 16;
+  }();
+  return v;
+}
+
+// separable blur, register-streaming kernel; `tm` must be built for BL2_TW x BL2_TH tiles
+hipError_t orbx_launch_blur2(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
+                             const uint8_t* d_src, uint8_t* d_dst, int first_level) {
+  dim3 grid(tm.begin[plan.nlevels], n_frames);
+  if (orbx_blur2_rows_per_wave() == 32)
+    hipLaunchKernelGGL(k_blur2<32>, grid, dim3(256), 0, s, plan, tm, d_src, d_dst, first_level);
+  else
+    hipLaunchKernelGGL(k_blur2<16>, grid, dim3(256), 0, s, plan, tm, d_src, d_dst, first_level);
   return ORBX_LAUNCH_CHECK();
 }
 
