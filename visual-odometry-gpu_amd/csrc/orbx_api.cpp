@@ -67,7 +67,7 @@ struct orbx_ctx {
   // geometry for the current frame size, and for the largest size (capacity)
   OrbxPlan plan{};
   OrbxPlan plan_max{};
-  OrbxTileMap tm_pyr{}, tm_blur{}, tm_blur2{}, tm_fast{};
+  OrbxTileMap tm_pyr{}, tm_pyr2{}, tm_blur{}, tm_blur2{}, tm_fast{};
   std::vector<OrbxResizeTap> h_taps;
   int plan_w = 0, plan_h = 0;
 
@@ -321,12 +321,25 @@ int set_plan(orbx_ctx* c, int w, int h) {
                       hipMemcpyHostToDevice));
   c->plan = plan;
   make_tilemap(plan, ORBX_PYR_TW, ORBX_PYR_TH, true, &c->tm_pyr);
+  make_tilemap(plan, ORBX_PYR2_TW, ORBX_PYR2_TH, true, &c->tm_pyr2);
   make_tilemap(plan, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &c->tm_blur);
   make_tilemap(plan, ORBX_BLUR2_TW, 4 * orbx_blur2_rows_per_wave(), true, &c->tm_blur2);
   make_tilemap(plan, ORBX_FAST_TW, ORBX_FAST_TH, false, &c->tm_fast);
   c->plan_w = w;
   c->plan_h = h;
   return ORBX_OK;
+}
+
+// ORBX_PYR_IMPL=1 forces the first-generation pyramid kernel (A/B timing)
+hipError_t launch_pyramid_auto(orbx_ctx* c, hipStream_t s, int n, const uint8_t* d_in, int in_stride,
+                               size_t in_frame_stride) {
+  static const int impl = [] {
+    const char* e = getenv("ORBX_PYR_IMPL");
+    return e ? atoi(e) : 2;
+  }();
+  if (impl == 1)
+    return orbx_launch_pyramid(s, c->plan, c->tm_pyr, n, d_in, in_stride, in_frame_stride, c->d_taps, c->d_pyr);
+  return orbx_launch_pyramid2(s, c->plan, c->tm_pyr2, n, d_in, in_stride, in_frame_stride, c->d_taps, c->d_pyr);
 }
 
 int fast_ablate() {  // timing diagnostics only: results are wrong when non-zero
@@ -361,7 +374,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   const bool t = c->timing;
   int e = 0;
   if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
-  HIPCHK(c, orbx_launch_pyramid(s, P, c->tm_pyr, n, d_frames, row_stride, frame_stride, c->d_taps, c->d_pyr));
+  HIPCHK(c, launch_pyramid_auto(c, s, n, d_frames, row_stride, frame_stride));
   if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
   if (blur_enabled(c))
     HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->tm_blur2, n, c->d_pyr, c->d_pyr_blur,
@@ -1019,8 +1032,7 @@ int orbx_build_pyramid_level(orbx_ctx* c, const uint8_t* image, int width, int h
   if ((st = set_plan(c, width, height)) != ORBX_OK) return st;
   const OrbxPlan& P = c->plan;
   HIPCHK(c, hipMemcpy2DAsync(c->d_in, width, image, stride, width, height, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, orbx_launch_pyramid(c->stream, P, c->tm_pyr, 1, c->d_in, width, (size_t)width * height, c->d_taps,
-                                c->d_pyr));
+  HIPCHK(c, launch_pyramid_auto(c, c->stream, 1, c->d_in, width, (size_t)width * height));
   if (blur_enabled(c))
     HIPCHK(c, launch_blur_auto(c->stream, P, c->tm_blur, c->tm_blur2, 1, c->d_pyr, c->d_pyr_blur,
                                c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));

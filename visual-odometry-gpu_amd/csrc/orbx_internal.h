@@ -68,6 +68,9 @@ int orbx_blur2_rows_per_wave();  // 16 or 32; tile height of k_blur2 = 4x this
 // tile geometry of the pyramid kernel (each thread: 4 px)
 #define ORBX_PYR_TW 256
 #define ORBX_PYR_TH 4
+// k_pyramid2: a wave owns 256 x 4 pixels, a workgroup 256 x 16
+#define ORBX_PYR2_TW 256
+#define ORBX_PYR2_TH 16
 
 #define ORBX_MAX_SELECT 8192  // largest per-level FAST cap the select kernel ranks in LDS
 
@@ -76,6 +79,9 @@ int orbx_blur2_rows_per_wave();  // 16 or 32; tile height of k_blur2 = 4x this
 hipError_t orbx_launch_pyramid(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
                                const uint8_t* d_in, int in_stride, size_t in_frame_stride,
                                const OrbxResizeTap* d_taps, uint8_t* d_pyr);
+hipError_t orbx_launch_pyramid2(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
+                                const uint8_t* d_in, int in_stride, size_t in_frame_stride,
+                                const OrbxResizeTap* d_taps, uint8_t* d_pyr);
 hipError_t orbx_launch_blur(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
                             const uint8_t* d_src, uint8_t* d_dst, int first_level, int kind);
 hipError_t orbx_launch_blur2(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,

@@ -120,6 +120,104 @@ __global__ __launch_bounds__(256) void k_pyramid(OrbxPlan plan, OrbxTileMap tm, 
 }
 
 // ---------------------------------------------------------------------------
+// 1b. pyramid, second generation.  The first kernel is latency-bound: 416k
+//     short waves, each with two dependent memory round trips (tap table ->
+//     pixel gathers).  Here a wave owns 256 x 4 output pixels: the row index
+//     is wave-uniform, so the y tap and the two source-row bases are scalar
+//     loads / SGPR addresses; the four x taps of a lane are loaded once and
+//     reused for four rows; all 32 pixel-pair gathers of a lane are issued
+//     before the first is consumed.
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+#define PYR2_ROWS 4  // output rows per wave
+
+__global__ __launch_bounds__(256) void k_pyramid2(OrbxPlan plan, OrbxTileMap tm, const uint8_t* __restrict__ in,
+                                                  int in_stride, size_t in_frame_stride,
+                                                  const OrbxResizeTap* __restrict__ taps,
+                                                  uint8_t* __restrict__ pyr) {
+  int l, tx, ty;
+  decode_tile(tm, plan.nlevels, l, tx, ty);
+  const OrbxLevel& L = plan.L[l];
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint8_t* src = in + (size_t)f * in_frame_stride;
+  const int x = tx * 256 + lane * 4;
+  const int yb = ty * (4 * PYR2_ROWS) + wave * PYR2_ROWS;
+  if (yb >= L.h) return;  // whole wave
+  const int pitch = L.pitch, w = L.w;
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+      pyr + (size_t)f * plan.frame_bytes + L.img_off, 0, pitch * L.h, 0x00020000);
+  const uint32_t voff_st = x < pitch ? (uint32_t)x : 0xffffffffu;
+  const int nvalid = w - x;
+  const uint32_t vmask = nvalid >= 4 ? 0xffffffffu : nvalid <= 0 ? 0u : ((1u << (8 * nvalid)) - 1u);
+
+  if (l == 0) {  // level 0 = the input frame (src/orb.cpp:112), re-pitched
+#pragma unroll
+    for (int r = 0; r < PYR2_ROWS; r++) {
+      const int y = yb + r;
+      if (y < L.h) {
+        const uint8_t* row = src + (size_t)y * in_stride;
+        uint32_t v = 0;
+        if (nvalid >= 4) {
+          v = *reinterpret_cast<const u32_unaligned*>(row + x);
+        } else if (nvalid > 0) {  // last dword of the row: never read past it
+          for (int k = 0; k < nvalid; k++) v |= (uint32_t)row[x + k] << (8 * k);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(v, rout, voff_st, y * pitch, 0);
+      }
+    }
+    return;
+  }
+
+  // x taps of this lane's four pixels (zero taps for lanes right of the image)
+  uint32_t ofs[4] = {0, 0, 0, 0}, cc[4] = {0, 0, 0, 0};
+  if (nvalid > 0) {
+    const uint4* tp = reinterpret_cast<const uint4*>(taps + L.xtab_off + x);
+    const uint4 t01 = tp[0], t23 = tp[1];
+    ofs[0] = t01.x; ofs[1] = t01.z; ofs[2] = t23.x; ofs[3] = t23.z;
+    cc[0] = t01.y; cc[1] = t01.w; cc[2] = t23.y; cc[3] = t23.w;
+  }
+  // gather phase: 2 source rows x 4 pixel pairs x 4 output rows
+  uint32_t p0[PYR2_ROWS][4], p1[PYR2_ROWS][4];
+  int b0[PYR2_ROWS], b1[PYR2_ROWS];
+#pragma unroll
+  for (int r = 0; r < PYR2_ROWS; r++) {
+    const int y = min(yb + r, L.h - 1);  // rows past the level repeat the last one (not stored)
+    const OrbxResizeTap ty_ = taps[L.ytab_off + y];  // wave-uniform -> scalar load
+    const int sy0 = min(max(ty_.ofs, 0), plan.h0 - 1), sy1 = min(max(ty_.ofs + 1, 0), plan.h0 - 1);
+    const uint8_t* S0 = src + (size_t)sy0 * in_stride;
+    const uint8_t* S1 = src + (size_t)sy1 * in_stride;
+    b0[r] = ty_.c0;
+    b1[r] = ty_.c1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      // ofs <= w0-2 always (host table): one unaligned 16-bit load fetches src[ofs], src[ofs+1]
+      p0[r][k] = *reinterpret_cast<const u16_unaligned*>(S0 + ofs[k]);
+      p1[r][k] = *reinterpret_cast<const u16_unaligned*>(S1 + ofs[k]);
+    }
+  }
+  int c0[4], c1[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    c0[k] = (int)(cc[k] & 0xffffu);
+    c1[k] = (int)(cc[k] >> 16);
+  }
+#pragma unroll
+  for (int r = 0; r < PYR2_ROWS; r++) {
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int r0 = (int)(p0[r][k] & 0xffu) * c0[k] + (int)(p0[r][k] >> 8) * c1[k];
+      const int r1 = (int)(p1[r][k] & 0xffu) * c0[k] + (int)(p1[r][k] >> 8) * c1[k];
+      const uint32_t v = (uint32_t)((((b0[r] * (r0 >> 4)) >> 16) + ((b1[r] * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+      out |= v << (8 * k);
+    }
+    const int y = yb + r;
+    if (y < L.h) __builtin_amdgcn_raw_buffer_store_b32(out & vmask, rout, voff_st, y * pitch, 0);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // 2. 5x5 Gaussian blur, REFLECT_101.
 //    kind 0: separable [1 4 6 4 1]/16 twice then round-half-even
 //            == rne(sum_ij w_i w_j p / 256)   (src/cuda/GaussianBlur1D.cu:34-163;
@@ -564,39 +662,76 @@ __global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxTileMap tm
   if (tid == 0) s_qn = 0;
   __syncthreads();
 
-  // phase 2: 4-point pre-test, one dword (4 pixels) per lane (src/orb_cpu.cpp:39-58)
+  // phase 2: 4-point pre-test, one dword (4 pixels) per lane (src/orb_cpu.cpp:39-58).
+  // Each lane keeps the candidate bits of all its items in one register; the
+  // candidates are compacted into the LDS queue ONCE per tile (wave prefix sum
+  // of the popcounts + one LDS atomic per wave).
+  constexpr int NIT = (N_ITEMS + 255) / 256;
+  static_assert(NIT * 4 <= 32, "candidate bits must fit one register");
+  uint32_t cand_bits = 0;
   if (!(fp.ablate & 2)) {
     const uint32_t t_hi = (uint32_t)thr * 0x00010001u;
     // the reference's else-if makes "darker" strict when threshold == 0
     const uint32_t t_lo = (uint32_t)(thr == 0 ? 1 : thr) * 0x00010001u;
-    for (int i = tid; i < N_ITEMS; i += 256) {
-      const int sy = i / F2_DCOLS, dc = i - sy * F2_DCOLS;
-      const int gy = y0 - R + sy, gx = x0 - 4 + 4 * dc;
-      uint32_t m4 = 0;
-      if (gy >= 3 && gy < L.h - 3 && gx + 3 >= 3 && gx < L.w - 3) {
-        const uint32_t* p = s_img32 + (sy + 3) * F2_IMG_DW + dc + 1;
-        const uint32_t C = p[0], Lw = p[-1], Rw = p[1], Nw = p[-3 * F2_IMG_DW], Sw = p[3 * F2_IMG_DW];
-        // even pixels (0,2) and odd pixels (1,3) of the dword as 16-bit lanes
-        const uint32_t ce = __builtin_amdgcn_perm(C, C, 0x0c020c00u), co = __builtin_amdgcn_perm(C, C, 0x0c030c01u);
-        const uint32_t ne = __builtin_amdgcn_perm(Nw, Nw, 0x0c020c00u), no = __builtin_amdgcn_perm(Nw, Nw, 0x0c030c01u);
-        const uint32_t se = __builtin_amdgcn_perm(Sw, Sw, 0x0c020c00u), so = __builtin_amdgcn_perm(Sw, Sw, 0x0c030c01u);
-        // east = x+3: px0 -> C.b3, px1 -> R.b0, px2 -> R.b1, px3 -> R.b2   (perm bytes: 0-3 = 2nd arg, 4-7 = 1st)
-        const uint32_t ee = __builtin_amdgcn_perm(Rw, C, 0x0c050c03u), eo = __builtin_amdgcn_perm(Rw, C, 0x0c060c04u);
-        // west = x-3: px0 -> L.b1, px1 -> L.b2, px2 -> L.b3, px3 -> C.b0
-        const uint32_t we = __builtin_amdgcn_perm(C, Lw, 0x0c030c01u), wo = __builtin_amdgcn_perm(C, Lw, 0x0c040c02u);
-        const uint32_t re = pretest_pk(ce, ne, ee, se, we, t_hi, t_lo);
-        const uint32_t ro = pretest_pk(co, no, eo, so, wo, t_hi, t_lo);
-        const uint32_t r2 = ((re >> 15) | (ro >> 14)) & 0x00030003u;  // bit0 px0, bit1 px1, bit16 px2, bit17 px3
-        m4 = (r2 | (r2 >> 14)) & 0xfu;
-        // pixels outside [3, w-3) never become corners
-        const int lo = max(0, 3 - gx), hi = min(4, L.w - 3 - gx);
-        m4 &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-      }
-      if (fp.ablate & 1) m4 = 0;  // diagnostics: no candidates -> phases 3/4 are empty
-      const int pos0 = sy * F2_SC_PITCH + 4 * dc;
+    // tiles whose whole score region lies inside [3,w-3) x [3,h-3) skip the per-item range tests
+    const bool interior = (x0 - 4 >= 3) && (x0 + F2_SC_PITCH - 4 <= L.w - 3) && (y0 - R >= 3) &&
+                          (y0 - R + SC_ROWS <= L.h - 3);
+    int sy = tid / F2_DCOLS, dc = tid - sy * F2_DCOLS;
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (m4 & (1u << k)) s_queue[atomicAdd(&s_qn, 1)] = (uint16_t)(pos0 + k);
+    for (int j = 0; j < NIT; j++) {
+      if (tid + 256 * j < N_ITEMS) {
+        const int gy = y0 - R + sy, gx = x0 - 4 + 4 * dc;
+        if (interior || (gy >= 3 && gy < L.h - 3 && gx >= 0 && gx < L.w - 3)) {
+          const uint32_t* p = s_img32 + (sy + 3) * F2_IMG_DW + dc + 1;
+          const uint32_t C = p[0], Lw = p[-1], Rw = p[1], Nw = p[-3 * F2_IMG_DW], Sw = p[3 * F2_IMG_DW];
+          // even pixels (0,2) and odd pixels (1,3) of the dword as 16-bit lanes
+          const uint32_t ce = __builtin_amdgcn_perm(C, C, 0x0c020c00u), co = __builtin_amdgcn_perm(C, C, 0x0c030c01u);
+          const uint32_t ne = __builtin_amdgcn_perm(Nw, Nw, 0x0c020c00u), no = __builtin_amdgcn_perm(Nw, Nw, 0x0c030c01u);
+          const uint32_t se = __builtin_amdgcn_perm(Sw, Sw, 0x0c020c00u), so = __builtin_amdgcn_perm(Sw, Sw, 0x0c030c01u);
+          // east = x+3: px0 -> C.b3, px1 -> R.b0, px2 -> R.b1, px3 -> R.b2   (perm bytes: 0-3 = 2nd arg, 4-7 = 1st)
+          const uint32_t ee = __builtin_amdgcn_perm(Rw, C, 0x0c050c03u), eo = __builtin_amdgcn_perm(Rw, C, 0x0c060c04u);
+          // west = x-3: px0 -> L.b1, px1 -> L.b2, px2 -> L.b3, px3 -> C.b0
+          const uint32_t we = __builtin_amdgcn_perm(C, Lw, 0x0c030c01u), wo = __builtin_amdgcn_perm(C, Lw, 0x0c040c02u);
+          const uint32_t re = pretest_pk(ce, ne, ee, se, we, t_hi, t_lo);
+          const uint32_t ro = pretest_pk(co, no, eo, so, wo, t_hi, t_lo);
+          const uint32_t r2 = ((re >> 15) | (ro >> 14)) & 0x00030003u;  // bit0 px0, bit1 px1, bit16 px2, bit17 px3
+          uint32_t m4 = (r2 | (r2 >> 14)) & 0xfu;
+          if (!interior) {  // pixels outside [3, w-3) never become corners
+            const int lo = max(0, 3 - gx), hi = min(4, L.w - 3 - gx);
+            m4 &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+          }
+          cand_bits |= m4 << (4 * j);
+        }
+      }
+      // item i + 256: 256 = 14 * 18 + 4
+      sy += 256 / F2_DCOLS;
+      dc += 256 % F2_DCOLS;
+      if (dc >= F2_DCOLS) {
+        dc -= F2_DCOLS;
+        sy += 1;
+      }
+    }
+    if (fp.ablate & 1) cand_bits = 0;  // diagnostics: no candidates -> phases 3/4 are empty
+  }
+  {
+    const int lane = tid & 63;
+    const int cnt = __popc(cand_bits);
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    int wbase = 0;
+    if (lane == 63) wbase = atomicAdd(&s_qn, incl);
+    wbase = __shfl(wbase, 63, 64);
+    int pos = wbase + incl - cnt;
+    while (cand_bits) {
+      const int bpos = __ffs(cand_bits) - 1;
+      cand_bits &= cand_bits - 1;
+      const int i = tid + 256 * (bpos >> 2);
+      const int isy = i / F2_DCOLS, idc = i - isy * F2_DCOLS;
+      s_queue[pos++] = (uint16_t)(isy * F2_SC_PITCH + 4 * idc + (bpos & 3));
     }
   }
   __syncthreads();
@@ -757,6 +892,68 @@ __device__ __forceinline__ float harris_at(const uint8_t* img, int w, int h, int
   return __fsub_rn(det, __fmul_rn(__fmul_rn(kk, trace), trace));
 }
 
+// Fast path for interior keypoints and window K <= 7: the (K+2)^2 pixel
+// neighbourhood is fetched once with 3 aligned dword loads per row and
+// byte-aligned in registers (v_alignbyte), pixels are converted with
+// v_cvt_f32_ubyteN, Sobel sums are shared between neighbouring taps.  Every
+// intermediate is a small exact integer in float, and the weighted
+// accumulation keeps the (i,j) order and the separate mul/mul/add roundings of
+// harris_at, so the result is bit-identical to it.
+template <int K>
+__device__ __forceinline__ float harris_fast(const uint8_t* img, int w, int h, int pitch, int x, int y,
+                                             const float* __restrict__ g, float kk) {
+  constexpr int r = K / 2, P = K + 2;
+  const int xs = x - r - 1;
+  const int a0 = xs & ~3, off = xs - a0;
+  float p[P][P];
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(img + (size_t)(y - r - 1 + i) * pitch + a0);
+    const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];
+    const uint32_t q0 = __builtin_amdgcn_alignbyte(d1, d0, off), q1 = __builtin_amdgcn_alignbyte(d2, d1, off);
+    const uint32_t q2 = d2 >> (8 * off);
+    const uint32_t q[3] = {q0, q1, q2};
+#pragma unroll
+    for (int j = 0; j < P; j++) p[i][j] = (float)((q[j >> 2] >> (8 * (j & 3))) & 0xffu);
+  }
+  // vertical [1 2 1] (for gx) and horizontal [1 2 1] (for gy) partial sums
+  float vs[K][P], hs[P][K];
+#pragma unroll
+  for (int i = 0; i < K; i++)
+#pragma unroll
+    for (int j = 0; j < P; j++) vs[i][j] = p[i][j] + 2.0f * p[i + 1][j] + p[i + 2][j];
+#pragma unroll
+  for (int i = 0; i < P; i++)
+#pragma unroll
+    for (int j = 0; j < K; j++) hs[i][j] = p[i][j] + 2.0f * p[i][j + 1] + p[i][j + 2];
+  float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+  for (int i = 0; i < K; i++)
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const float gx = vs[i][j + 2] - vs[i][j];
+      const float gy = hs[i + 2][j] - hs[i][j];
+      const float wgt = g[i * K + j];
+      a = __fadd_rn(a, __fmul_rn(__fmul_rn(gx, gx), wgt));
+      c = __fadd_rn(c, __fmul_rn(__fmul_rn(gy, gy), wgt));
+      b = __fadd_rn(b, __fmul_rn(__fmul_rn(gx, gy), wgt));
+    }
+  const float det = __fsub_rn(__fmul_rn(a, c), __fmul_rn(b, b));
+  const float trace = __fadd_rn(a, c);
+  return __fsub_rn(det, __fmul_rn(__fmul_rn(kk, trace), trace));
+}
+
+__device__ __forceinline__ float harris_any(const uint8_t* img, int w, int h, int pitch, int x, int y,
+                                            const float* __restrict__ g, int K, float kk) {
+  const int m = K / 2 + 1;  // the fast path needs the whole (K+2)^2 window inside the image
+  if (x >= m && y >= m && x < w - m && y < h - m) {
+    if (K == 7) return harris_fast<7>(img, w, h, pitch, x, y, g, kk);
+    if (K == 5) return harris_fast<5>(img, w, h, pitch, x, y, g, kk);
+    if (K == 3) return harris_fast<3>(img, w, h, pitch, x, y, g, kk);
+  }
+  return harris_at(img, w, h, pitch, x, y, g, K, kk);
+}
+
 __global__ __launch_bounds__(256) void k_harris(OrbxPlan plan, const uint8_t* __restrict__ pyr,
                                                 const orbx_keypoint* __restrict__ cand,
                                                 const int32_t* __restrict__ cand_count,
@@ -773,7 +970,7 @@ __global__ __launch_bounds__(256) void k_harris(OrbxPlan plan, const uint8_t* __
   if (idx >= cand_count[f * plan.nlevels + l]) return;
   const orbx_keypoint kp = cand[(size_t)f * plan.cand_total + j];
   const uint8_t* img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
-  resp[(size_t)f * plan.cand_total + j] = harris_at(img, L.w, L.h, L.pitch, kp.x, kp.y, gauss, K, kk);
+  resp[(size_t)f * plan.cand_total + j] = harris_any(img, L.w, L.h, L.pitch, kp.x, kp.y, gauss, K, kk);
 }
 
 __global__ __launch_bounds__(256) void k_harris_flat(const uint8_t* __restrict__ img, int w, int h, int pitch,
@@ -782,7 +979,7 @@ __global__ __launch_bounds__(256) void k_harris_flat(const uint8_t* __restrict__
                                                      float* __restrict__ resp) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= nkp) return;
-  resp[j] = harris_at(img, w, h, pitch, kps[j].x, kps[j].y, gauss, K, kk);
+  resp[j] = harris_any(img, w, h, pitch, kps[j].x, kps[j].y, gauss, K, kk);
 }
 
 // ---------------------------------------------------------------------------
@@ -896,13 +1093,25 @@ __device__ __forceinline__ void describe_wave(const DescJob& jb, DescLds& lds, i
   const int ax0 = px0 & ~3;  // floor to a multiple of 4 (two's complement)
   const int off = px0 - ax0;
   if (jb.valid) {
-    for (int i = lane; i < DESC_ROWS * (DESC_PITCH / 4); i += 64) {
-      const int row = i / (DESC_PITCH / 4), c = i - row * (DESC_PITCH / 4);
-      const int gy = py0 + row, gx = ax0 + 4 * c;
-      uint32_t v = 0;
-      if (gy >= 0 && gy < jb.h && gx >= 0 && gx + 4 <= jb.pitch)
-        v = *reinterpret_cast<const uint32_t*>(jb.img + (size_t)gy * jb.pitch + gx);
-      lds.patch[i] = v;
+    // item i = lane + 64k -> (row, dword column); 64 = 5 * 12 + 4 gives the increments
+    int row = lane / (DESC_PITCH / 4), c = lane - row * (DESC_PITCH / 4);
+#pragma unroll
+    for (int k = 0; k < (DESC_ROWS * (DESC_PITCH / 4) + 63) / 64; k++) {
+      const int i = lane + 64 * k;
+      if (i < DESC_ROWS * (DESC_PITCH / 4)) {
+        const int gy = py0 + row, gx = ax0 + 4 * c;
+        uint32_t v = 0;
+        // gx, pitch are multiples of 4: (unsigned)gx < pitch  <=>  0 <= gx && gx + 4 <= pitch
+        if ((unsigned)gy < (unsigned)jb.h && (unsigned)gx < (unsigned)jb.pitch)
+          v = *reinterpret_cast<const uint32_t*>(jb.img + (uint32_t)(gy * jb.pitch + gx));
+        lds.patch[i] = v;
+      }
+      row += 5;
+      c += 4;
+      if (c >= DESC_PITCH / 4) {
+        c -= DESC_PITCH / 4;
+        row += 1;
+      }
     }
   }
   __syncthreads();
@@ -939,32 +1148,51 @@ __device__ __forceinline__ void describe_wave(const DescJob& jb, DescLds& lds, i
   angle_out = angle;
   if (!do_brief) return;
 
-  // pass 1: horizontal 5-sums, 4 per item (row r, dword group g)
+  // pass 1: horizontal 5-sums, 4 per item (row r, dword group g); item i = lane + 64k,
+  // 64 = 6 * 10 + 4 gives the increments
   if (jb.valid) {
-    for (int i = lane; i < DESC_ROWS * 10; i += 64) {
-      const int r = i / 10, g = i - r * 10;
-      const uint32_t d0 = lds.patch[r * (DESC_PITCH / 4) + g], d1 = lds.patch[r * (DESC_PITCH / 4) + g + 1];
-      const uint32_t b0 = d0 & 0xff, b1 = (d0 >> 8) & 0xff, b2 = (d0 >> 16) & 0xff, b3 = d0 >> 24;
-      const uint32_t b4 = d1 & 0xff, b5 = (d1 >> 8) & 0xff, b6 = (d1 >> 16) & 0xff, b7 = d1 >> 24;
-      const uint32_t s0 = b0 + b1 + b2 + b3 + b4;
-      const uint32_t s1 = s0 - b0 + b5, s2 = s1 - b1 + b6, s3 = s2 - b2 + b7;
-      *reinterpret_cast<uint2*>(&lds.hs[r * DESC_HP + 4 * g]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+    int r = lane / 10, g = lane - r * 10;
+#pragma unroll
+    for (int k = 0; k < (DESC_ROWS * 10 + 63) / 64; k++) {
+      if (lane + 64 * k < DESC_ROWS * 10) {
+        const uint32_t d0 = lds.patch[r * (DESC_PITCH / 4) + g], d1 = lds.patch[r * (DESC_PITCH / 4) + g + 1];
+        const uint32_t b0 = d0 & 0xff, b1 = (d0 >> 8) & 0xff, b2 = (d0 >> 16) & 0xff, b3 = d0 >> 24;
+        const uint32_t b4 = d1 & 0xff, b5 = (d1 >> 8) & 0xff, b6 = (d1 >> 16) & 0xff, b7 = d1 >> 24;
+        const uint32_t s0 = b0 + b1 + b2 + b3 + b4;
+        const uint32_t s1 = s0 - b0 + b5, s2 = s1 - b1 + b6, s3 = s2 - b2 + b7;
+        *reinterpret_cast<uint2*>(&lds.hs[r * DESC_HP + 4 * g]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+      }
+      r += 6;
+      g += 4;
+      if (g >= 10) {
+        g -= 10;
+        r += 1;
+      }
     }
   }
   __syncthreads();
   // pass 2: vertical 5-sums of the horizontal sums
   if (jb.valid) {
-    for (int i = lane; i < DESC_BROWS * 10; i += 64) {
-      const int r = i / 10, g = i - r * 10;
-      const uint2* hp = reinterpret_cast<const uint2*>(&lds.hs[r * DESC_HP + 4 * g]);
-      uint2 acc = hp[0];
+    int r = lane / 10, g = lane - r * 10;
 #pragma unroll
-      for (int k = 1; k < 5; k++) {
-        const uint2 v = hp[k * (DESC_HP / 4)];
-        acc.x = pk_add(acc.x, v.x);
-        acc.y = pk_add(acc.y, v.y);
+    for (int k = 0; k < (DESC_BROWS * 10 + 63) / 64; k++) {
+      if (lane + 64 * k < DESC_BROWS * 10) {
+        const uint2* hp = reinterpret_cast<const uint2*>(&lds.hs[r * DESC_HP + 4 * g]);
+        uint2 acc = hp[0];
+#pragma unroll
+        for (int q = 1; q < 5; q++) {
+          const uint2 v = hp[q * (DESC_HP / 4)];
+          acc.x = pk_add(acc.x, v.x);
+          acc.y = pk_add(acc.y, v.y);
+        }
+        *reinterpret_cast<uint2*>(&lds.box[r * DESC_HP + 4 * g]) = acc;
       }
-      *reinterpret_cast<uint2*>(&lds.box[r * DESC_HP + 4 * g]) = acc;
+      r += 6;
+      g += 4;
+      if (g >= 10) {
+        g -= 10;
+        r += 1;
+      }
     }
   }
   __syncthreads();
@@ -1141,6 +1369,15 @@ hipError_t orbx_launch_pyramid(hipStream_t s, const OrbxPlan& plan, const OrbxTi
                                const OrbxResizeTap* d_taps, uint8_t* d_pyr) {
   dim3 grid(tm.begin[plan.nlevels], n_frames);
   hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, s, plan, tm, d_in, in_stride, in_frame_stride, d_taps, d_pyr);
+  return ORBX_LAUNCH_CHECK();
+}
+
+// `tm` must be built for 256 x 16 tiles
+hipError_t orbx_launch_pyramid2(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
+                                const uint8_t* d_in, int in_stride, size_t in_frame_stride,
+                                const OrbxResizeTap* d_taps, uint8_t* d_pyr) {
+  dim3 grid(tm.begin[plan.nlevels], n_frames);
+  hipLaunchKernelGGL(k_pyramid2, grid, dim3(256), 0, s, plan, tm, d_in, in_stride, in_frame_stride, d_taps, d_pyr);
   return ORBX_LAUNCH_CHECK();
 }
 
