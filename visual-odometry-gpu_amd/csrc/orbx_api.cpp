@@ -67,7 +67,9 @@ struct orbx_ctx {
   // geometry for the current frame size, and for the largest size (capacity)
   OrbxPlan plan{};
   OrbxPlan plan_max{};
-  OrbxTileMap tm_pyr{}, tm_pyr2{}, tm_blur{}, tm_blur2{}, tm_fast{};
+  OrbxTileMap tm_pyr{}, tm_pyr2{}, tm_blur{}, tm_blur2{};
+  OrbxBandMap bm_fast{};
+  unsigned long long* d_row_stat = nullptr;
   std::vector<OrbxResizeTap> h_taps;
   int plan_w = 0, plan_h = 0;
 
@@ -163,6 +165,36 @@ void make_tilemap(const OrbxPlan& plan, int tw, int th, bool use_pitch, OrbxTile
     acc += tx * ty;
   }
   for (int l = plan.nlevels; l <= ORBX_MAX_LEVELS; l++) tm->begin[l] = acc;
+}
+
+// band-major order of the FAST tiles (levels shrink with the level index, so the
+// levels that have a tile row b are always a prefix of the level list)
+int make_bandmap(const OrbxPlan& plan, OrbxBandMap* bm, std::string* why) {
+  std::memset(bm, 0, sizeof(*bm));
+  int nb = 0;
+  for (int l = 0; l < plan.nlevels; l++) {
+    bm->tiles_x[l] = (plan.L[l].w + ORBX_FAST_TW - 1) / ORBX_FAST_TW;
+    bm->tiles_y[l] = (plan.L[l].h + ORBX_FAST_TH - 1) / ORBX_FAST_TH;
+    bm->xprefix[l + 1] = bm->xprefix[l] + bm->tiles_x[l];
+    if (l > 0 && bm->tiles_y[l] > bm->tiles_y[l - 1]) {
+      *why = "pyramid levels must not grow with the level index";
+      return ORBX_ERR_UNSUPPORTED;
+    }
+    nb = std::max(nb, bm->tiles_y[l]);
+  }
+  if (nb > ORBX_MAX_BANDS) {
+    *why = "image taller than ORBX_MAX_BANDS FAST tile rows";
+    return ORBX_ERR_UNSUPPORTED;
+  }
+  bm->nbands = nb;
+  int acc = 0;
+  for (int b = 0; b < nb; b++) {
+    bm->band_begin[b] = acc;
+    for (int l = 0; l < plan.nlevels; l++)
+      if (bm->tiles_y[l] > b) acc += bm->tiles_x[l];
+  }
+  for (int b = nb; b <= ORBX_MAX_BANDS; b++) bm->band_begin[b] = acc;
+  return ORBX_OK;
 }
 
 int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string* why) {
@@ -324,7 +356,7 @@ int set_plan(orbx_ctx* c, int w, int h) {
   make_tilemap(plan, ORBX_PYR2_TW, ORBX_PYR2_TH, true, &c->tm_pyr2);
   make_tilemap(plan, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &c->tm_blur);
   make_tilemap(plan, ORBX_BLUR2_TW, 4 * orbx_blur2_rows_per_wave(), true, &c->tm_blur2);
-  make_tilemap(plan, ORBX_FAST_TW, ORBX_FAST_TH, false, &c->tm_fast);
+  if ((st = make_bandmap(plan, &c->bm_fast, &why)) != ORBX_OK) return fail(c, st, why);
   c->plan_w = w;
   c->plan_h = h;
   return ORBX_OK;
@@ -351,6 +383,24 @@ int fast_ablate() {  // timing diagnostics only: results are wrong when non-zero
 }
 
 bool blur_enabled(const orbx_ctx* c) { return c->p.blur_levels != ORBX_BLUR_NONE; }
+const uint8_t* final_pyr(const orbx_ctx* c);
+
+// FAST + NMS of the batched path.  Tiles that provably cannot contribute to the
+// first `cap` row-major survivors exit early (see decode_band in the kernels);
+// ORBX_FAST_EARLY=0 disables that (every tile does the full work).
+hipError_t launch_fast_whole(orbx_ctx* c, hipStream_t s, int n, OrbxFastParams fp) {
+  static const int early = [] {
+    const char* e = getenv("ORBX_FAST_EARLY");
+    return e ? atoi(e) : 1;
+  }();
+  unsigned long long* stat = nullptr;
+  if (early) {
+    stat = c->d_row_stat;
+    hipError_t e = hipMemsetAsync(stat, 0, (size_t)n * ORBX_MAX_LEVELS * ORBX_MAX_BANDS * 8, s);
+    if (e != hipSuccess) return e;
+  }
+  return orbx_launch_fast_nms(s, c->plan, c->bm_fast, n, final_pyr(c), fp, c->d_mask, nullptr, stat);
+}
 
 // separable kind -> register-streaming kernel; /273 kind -> LDS tile kernel.
 // ORBX_BLUR_IMPL=1 forces the first-generation kernel (A/B timing).
@@ -381,9 +431,9 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
                                c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
   if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
   OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2, fast_ablate()};
-  HIPCHK(c, orbx_launch_fast_nms(s, P, c->tm_fast, n, final_pyr(c), fp, c->d_mask, nullptr));
+  HIPCHK(c, launch_fast_whole(c, s, n, fp));
   if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
-  HIPCHK(c, orbx_launch_compact(s, P, n, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total));
+  HIPCHK(c, orbx_launch_compact(s, P, n, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total, 0));
   if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
   if (c->p.select_mode == ORBX_SELECT_HARRIS)
     HIPCHK(c, orbx_launch_harris(s, P, n, final_pyr(c), c->d_cand, c->d_cand_count, c->d_gauss,
@@ -516,7 +566,7 @@ void orbx_destroy(orbx_ctx* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* bufs[] = {c->d_in,   c->d_pyr,  c->d_pyr_blur, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total,
-                  c->d_resp, c->d_taps, c->d_gauss,    c->d_out};
+                  c->d_resp, c->d_taps, c->d_gauss,    c->d_out, c->d_row_stat};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_out) (void)hipHostFree(c->h_out);
@@ -583,6 +633,7 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
   if (p->blur_levels != ORBX_BLUR_NONE)
     CREATE_CHK(hipMalloc((void**)&c->d_pyr_blur, B * (size_t)M.frame_bytes + 256));
   CREATE_CHK(hipMalloc((void**)&c->d_mask, B * (size_t)M.mask_words * 8 + 256));
+  CREATE_CHK(hipMalloc((void**)&c->d_row_stat, B * ORBX_MAX_LEVELS * ORBX_MAX_BANDS * 8));
   CREATE_CHK(hipMalloc((void**)&c->d_cand, B * (size_t)std::max(M.cand_total, 1) * sizeof(orbx_keypoint)));
   CREATE_CHK(hipMalloc((void**)&c->d_cand_count, B * ORBX_MAX_LEVELS * sizeof(int32_t)));
   CREATE_CHK(hipMalloc((void**)&c->d_cand_total, B * ORBX_MAX_LEVELS * sizeof(int32_t)));
@@ -768,10 +819,10 @@ int orbx_bench_stage(orbx_ctx* c, int n_frames, int stage, int reps, float* avg_
                                    c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
         break;
       case ORBX_STAGE_FAST:
-        HIPCHK(c, orbx_launch_fast_nms(s, P, c->tm_fast, n_frames, final_pyr(c), fp, c->d_mask, nullptr));
+        HIPCHK(c, launch_fast_whole(c, s, n_frames, fp));
         break;
       case ORBX_STAGE_COMPACT:
-        HIPCHK(c, orbx_launch_compact(s, P, n_frames, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total));
+        HIPCHK(c, orbx_launch_compact(s, P, n_frames, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total, 0));
         break;
       default:
         return fail(c, ORBX_ERR_INVALID_ARG, "stage not benchmarkable in isolation");
@@ -797,14 +848,15 @@ int orbx_fast_score(orbx_ctx* c, const uint8_t* image, int width, int height, in
   st = upload_flat(c, c->s_img_a, image, width, height, stride, &pitch);
   if (st != ORBX_OK) return st;
   OrbxPlan P = flat_plan(width, height, 0);
-  OrbxTileMap tm;
-  make_tilemap(P, ORBX_FAST_TW, ORBX_FAST_TH, false, &tm);
+  OrbxBandMap bm;
+  std::string why;
+  if ((st = make_bandmap(P, &bm, &why)) != ORBX_OK) return fail(c, st, why);
   const size_t npx = (size_t)width * height;
   if ((st = ensure(c, c->s_u16, npx * 2)) != ORBX_OK) return st;
   if ((st = ensure(c, c->s_mask, (size_t)P.mask_words * 8)) != ORBX_OK) return st;
   OrbxFastParams fp{threshold, n, 0, 0};
-  HIPCHK(c, orbx_launch_fast_nms(c->stream, P, tm, 1, (const uint8_t*)c->s_img_a.p, fp,
-                                 (unsigned long long*)c->s_mask.p, (uint16_t*)c->s_u16.p));
+  HIPCHK(c, orbx_launch_fast_nms(c->stream, P, bm, 1, (const uint8_t*)c->s_img_a.p, fp,
+                                 (unsigned long long*)c->s_mask.p, (uint16_t*)c->s_u16.p, nullptr));
   std::vector<uint16_t> h(npx);
   HIPCHK(c, hipMemcpyAsync(h.data(), c->s_u16.p, npx * 2, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -819,7 +871,7 @@ static int compact_and_fetch(orbx_ctx* c, const OrbxPlan& P, int nfeatures, orbx
   if ((st = ensure(c, c->s_i32, 64)) != ORBX_OK) return st;
   int32_t* d_cnt = (int32_t*)c->s_i32.p;
   HIPCHK(c, orbx_launch_compact(c->stream, P, 1, (const unsigned long long*)c->s_mask.p, (orbx_keypoint*)c->s_kps.p,
-                                d_cnt, d_cnt + 1));
+                                d_cnt, d_cnt + 1, 1));
   int32_t h[2] = {0, 0};
   HIPCHK(c, hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -841,12 +893,14 @@ int orbx_fast(orbx_ctx* c, const uint8_t* image, int width, int height, int stri
   st = upload_flat(c, c->s_img_a, image, width, height, stride, &pitch);
   if (st != ORBX_OK) return st;
   OrbxPlan P = flat_plan(width, height, nfeatures);
-  OrbxTileMap tm;
-  make_tilemap(P, ORBX_FAST_TW, ORBX_FAST_TH, false, &tm);
+  OrbxBandMap bm;
+  std::string why;
+  if ((st = make_bandmap(P, &bm, &why)) != ORBX_OK) return fail(c, st, why);
   if ((st = ensure(c, c->s_mask, (size_t)P.mask_words * 8)) != ORBX_OK) return st;
   OrbxFastParams fp{threshold, n, nms_window / 2, 0};
-  HIPCHK(c, orbx_launch_fast_nms(c->stream, P, tm, 1, (const uint8_t*)c->s_img_a.p, fp,
-                                 (unsigned long long*)c->s_mask.p, nullptr));
+  // stage operator: exact totals are part of the contract -> no early exit
+  HIPCHK(c, orbx_launch_fast_nms(c->stream, P, bm, 1, (const uint8_t*)c->s_img_a.p, fp,
+                                 (unsigned long long*)c->s_mask.p, nullptr, nullptr));
   return compact_and_fetch(c, P, nfeatures, keypoints, count, total);
 }
 

@@ -44,6 +44,16 @@ struct OrbxTileMap {
   int32_t tiles_x[ORBX_MAX_LEVELS];
 };
 
+// band-major workgroup order of the FAST kernel (see decode_band)
+#define ORBX_MAX_BANDS 64
+struct OrbxBandMap {
+  int32_t nbands;
+  int32_t band_begin[ORBX_MAX_BANDS + 1];  // tiles PER FRAME before band b (+ total)
+  int32_t tiles_x[ORBX_MAX_LEVELS];
+  int32_t tiles_y[ORBX_MAX_LEVELS];
+  int32_t xprefix[ORBX_MAX_LEVELS + 1];  // prefix sums of tiles_x
+};
+
 // 8-bit bilinear resize coefficient (OpenCV-style 11-bit fixed point)
 struct OrbxResizeTap {
   int32_t ofs;     // source index (clamped)
@@ -86,12 +96,12 @@ hipError_t orbx_launch_blur(hipStream_t s, const OrbxPlan& plan, const OrbxTileM
                             const uint8_t* d_src, uint8_t* d_dst, int first_level, int kind);
 hipError_t orbx_launch_blur2(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
                              const uint8_t* d_src, uint8_t* d_dst, int first_level);
-hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
+hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxPlan& plan, const OrbxBandMap& bm, int n_frames,
                                 const uint8_t* d_pyr, OrbxFastParams fp, unsigned long long* d_mask,
-                                uint16_t* d_scores_dbg);
+                                uint16_t* d_scores_dbg, unsigned long long* d_row_stat);
 hipError_t orbx_launch_compact(hipStream_t s, const OrbxPlan& plan, int n_frames,
                                const unsigned long long* d_mask, orbx_keypoint* d_cand, int32_t* d_cand_count,
-                               int32_t* d_cand_total);
+                               int32_t* d_cand_total, int need_total);
 hipError_t orbx_launch_harris_flat(hipStream_t s, const uint8_t* d_img, int w, int h, int pitch,
                                    const orbx_keypoint* d_kps, int nkp, const float* d_gauss, int K, float kk,
                                    float* d_resp);

@@ -448,20 +448,14 @@ __global__ __launch_bounds__(256) void k_blur2(OrbxPlan plan, OrbxTileMap tm, co
 }
 
 // ---------------------------------------------------------------------------
-// 3. FAST-n segment test + score + (2r+1)^2 NMS, fused, one 64x32 tile per
-//    workgroup (src/orb_cpu.cpp:23-134; src/cuda/Fast.cu:30-209,
+// 3. FAST-n segment test + score + (2R+1)^2 NMS, fused, one 64x64 tile (+halo)
+//    per workgroup (src/orb_cpu.cpp:23-134; src/cuda/Fast.cu:30-209,
 //    src/cuda/NMS.cu:21-128).
-//    phase 1  row-coalesced dword loads of tile+halo into LDS
-//    phase 2  4-point pre-test on every pixel of the score region; survivors
-//             are compacted into an LDS queue with a wave ballot + popcount
-//    phase 3  dense full segment test + score on the queue (no divergence)
-//    phase 4  NMS out of the LDS score tile; one ballot per 64-pixel row
-//             becomes one u64 of the survivor mask
-#define FAST_IMG_PITCH 80                    // bytes: x0-8 .. x0+71
-#define FAST_IMG_ROWS (ORBX_FAST_TH + 12)    // r <= 3
-#define FAST_SC_PITCH 72                     // u16 entries: 64 + 2*3 rounded up
-#define FAST_SC_ROWS (ORBX_FAST_TH + 6)
-
+//    phase 1  row-coalesced 8-byte loads of tile+halo into LDS
+//    phase 2  4-point pre-test on every pixel, 4 pixels per lane (below)
+//    phase 3  dense full segment test + score on the compacted candidates
+//    phase 4  NMS for corners only; survivors set bits in an LDS mask
+//    phase 5  one 8-byte store per tile row of the survivor mask
 __device__ __forceinline__ bool has_run16(uint32_t m, int n) {
   uint32_t x = m | (m << 16);
   uint32_t acc = x;
@@ -474,115 +468,37 @@ __device__ __forceinline__ bool has_run16(uint32_t m, int n) {
   return (acc & 0xffffu) != 0;
 }
 
-template <bool WRITE_SCORES>
-__global__ __launch_bounds__(256) void k_fast_nms(OrbxPlan plan, OrbxTileMap tm, const uint8_t* __restrict__ pyr,
-                                                  OrbxFastParams fp, u64* __restrict__ mask,
-                                                  uint16_t* __restrict__ scores_dbg) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_img32[FAST_IMG_ROWS * (FAST_IMG_PITCH / 4)];
-  __shared__ __attribute__((aligned(16))) uint16_t s_score[FAST_SC_ROWS * FAST_SC_PITCH];
-  __shared__ uint16_t s_queue[FAST_SC_ROWS * (ORBX_FAST_TW + 6)];
-  __shared__ int s_qn;
-
-  int l, tx, ty;
-  decode_tile(tm, plan.nlevels, l, tx, ty);
-  const OrbxLevel& L = plan.L[l];
-  const int f = blockIdx.y;
-  const uint8_t* img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int r = fp.nms_radius, thr = fp.threshold;
-  const int x0 = tx * ORBX_FAST_TW, y0 = ty * ORBX_FAST_TH;
-  const int gy0 = y0 - 3 - r;
-  const int nrows = ORBX_FAST_TH + 6 + 2 * r;
-
-  // phase 1
-  for (int i = tid; i < nrows * (FAST_IMG_PITCH / 4); i += 256) {
-    const int row = i / (FAST_IMG_PITCH / 4), c = i - row * (FAST_IMG_PITCH / 4);
-    const int gy = gy0 + row, gx = x0 - 8 + 4 * c;
-    uint32_t v = 0;
-    if (gy >= 0 && gy < L.h && gx >= 0 && gx + 4 <= L.pitch)
-      v = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * L.pitch + gx);
-    s_img32[i] = v;
-  }
-  for (int i = tid; i < FAST_SC_ROWS * FAST_SC_PITCH / 2; i += 256) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
-  if (tid == 0) s_qn = 0;
-  __syncthreads();
-
-  // phase 2: pre-test (src/orb_cpu.cpp:39-58)
-  const uint8_t* s_img = reinterpret_cast<const uint8_t*>(s_img32);
-  const int SW = ORBX_FAST_TW + 2 * r, SH = ORBX_FAST_TH + 2 * r, N = SW * SH;
-  for (int base = 0; base < N; base += 256) {
-    const int i = base + tid;
-    bool cand = false;
-    if (i < N) {
-      const int sy = i / SW, sx = i - sy * SW;
-      const int gx = x0 - r + sx, gy = y0 - r + sy;
-      if (gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3) {
-        const uint8_t* p = s_img + (sy + 3) * FAST_IMG_PITCH + (sx - r + 8);
-        const int Ip = p[0], hi = Ip + thr, lo = Ip - thr;
-        const int a = p[-3 * FAST_IMG_PITCH], b = p[3], c = p[3 * FAST_IMG_PITCH], d = p[-3];
-        const int ba = a >= hi, bb = b >= hi, bc = c >= hi, bd = d >= hi;
-        const int br = ba + bb + bc + bd;
-        const int dk = (!ba && a <= lo) + (!bb && b <= lo) + (!bc && c <= lo) + (!bd && d <= lo);
-        cand = max(br, dk) >= 3;
-      }
-    }
-    const u64 m = __ballot(cand);
-    if (m) {
-      int wbase = 0;
-      if (lane == 0) wbase = atomicAdd(&s_qn, __popcll(m));
-      wbase = __shfl(wbase, 0, 64);
-      if (cand) s_queue[wbase + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
-    }
-  }
-  __syncthreads();
-
-  // phase 3: full segment test + score on compacted candidates (src/orb_cpu.cpp:61-101)
-  const int nq = s_qn;
-  for (int q = tid; q < nq; q += 256) {
-    const int i = s_queue[q];
-    const int sy = i / SW, sx = i - sy * SW;
-    const uint8_t* p = s_img + (sy + 3) * FAST_IMG_PITCH + (sx - r + 8);
-    const int Ip = p[0], hi = Ip + thr, lo = Ip - thr;
-    const int ring[16] = {p[-3 * FAST_IMG_PITCH],     p[-3 * FAST_IMG_PITCH + 1], p[-2 * FAST_IMG_PITCH + 2],
-                          p[-1 * FAST_IMG_PITCH + 3], p[3],                       p[FAST_IMG_PITCH + 3],
-                          p[2 * FAST_IMG_PITCH + 2],  p[3 * FAST_IMG_PITCH + 1],  p[3 * FAST_IMG_PITCH],
-                          p[3 * FAST_IMG_PITCH - 1],  p[2 * FAST_IMG_PITCH - 2],  p[FAST_IMG_PITCH - 3],
-                          p[-3],                      p[-FAST_IMG_PITCH - 3],     p[-2 * FAST_IMG_PITCH - 2],
-                          p[-3 * FAST_IMG_PITCH - 1]};
-    uint32_t bm = 0, dm = 0;
-    int score = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const int v = ring[k];
-      bm |= (uint32_t)(v >= hi) << k;
-      dm |= (uint32_t)(v <= lo) << k;
-      score += abs(Ip - v);
-    }
-    if (has_run16(bm, fp.n) || has_run16(dm, fp.n)) s_score[sy * FAST_SC_PITCH + sx] = (uint16_t)score;
-  }
-  __syncthreads();
-
-  // phase 4: NMS (keep iff score > 0 and no strictly greater neighbour; ties
-  // survive, src/orb_cpu.cpp:110-133) + survivor mask
-  u64* mrow = mask + (size_t)f * plan.mask_words + L.mask_off;
+// Workgroup order is BAND-MAJOR: all tiles of tile-row 0 of every level of
+// every frame come first, then tile-row 1, ... (levels shrink with the level
+// index, so the levels present in band b are a prefix 0..n_b-1).  Together
+// with the per-(frame, level, tile-row) statistics below this lets a tile
+// prove that it cannot contribute: keypoints are kept in ROW-MAJOR order up
+// to `cap` (src/orb_cpu.cpp:108-110, src/orb.cpp:63), so once the tile rows
+// strictly above a tile are complete and already hold >= cap survivors,
+// nothing in this tile can be among the first cap.  Such tiles write an empty
+// mask and exit.  The test only ever reads completed statistics, so it is
+// independent of dispatch order (a stale read just means "do the work").
+__device__ __forceinline__ void decode_band(const OrbxBandMap& bm, int nlevels, int n_frames, int& l, int& tx,
+                                            int& ty, int& f) {
+  const int id = blockIdx.x;
+  int b = 0;
 #pragma unroll 1
-  for (int k = 0; k < ORBX_FAST_TH / 4; k++) {
-    const int iy = (tid >> 6) + 4 * k, ix = lane;
-    const int gy = y0 + iy;
-    const uint16_t* sc = s_score + (iy + r) * FAST_SC_PITCH + ix + r;
-    const int s = sc[0];
-    bool keep = s > 0;
-    if (keep) {
-      for (int dy = -r; dy <= r; dy++)
-        for (int dx = -r; dx <= r; dx++) keep = keep && !(sc[dy * FAST_SC_PITCH + dx] > s);
-    }
-    const u64 m = __ballot(keep);
-    if (lane == 0 && gy < L.h) mrow[(size_t)gy * L.mask_wpr + tx] = m;
-    if (WRITE_SCORES) {
-      const int gx = x0 + ix;
-      if (gy < L.h && gx < L.w) scores_dbg[(size_t)gy * L.w + gx] = (uint16_t)s;
-    }
-  }
+  for (int i = 1; i < bm.nbands; i++)
+    if (id >= bm.band_begin[i] * n_frames) b = i;
+  const int rem = id - bm.band_begin[b] * n_frames;
+  int nl = 1;
+#pragma unroll 1
+  for (int i = 1; i < nlevels; i++)
+    if (bm.tiles_y[i] > b) nl = i + 1;
+  const int per_frame = bm.xprefix[nl];
+  f = rem / per_frame;
+  const int r2 = rem - f * per_frame;
+  l = 0;
+#pragma unroll 1
+  for (int i = 1; i < nl; i++)
+    if (r2 >= bm.xprefix[i]) l = i;
+  tx = r2 - bm.xprefix[l];
+  ty = b;
 }
 
 // ---------------------------------------------------------------------------
@@ -601,6 +517,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(OrbxPlan plan, OrbxTileMap tm,
 //     then stored with one 8-byte store per tile row;
 //   * 8-byte global loads for the tile.
 
+static_assert(ORBX_FAST_TH == 64, "phase 5 assumes one wave per tile column of mask words");
 #define F2_IMG_PITCH 80                 // bytes: x0-8 .. x0+71
 #define F2_IMG_DW (F2_IMG_PITCH / 4)    // 20
 #define F2_SC_PITCH 72                  // score tile columns: x0-4 .. x0+67
@@ -624,9 +541,10 @@ __device__ __forceinline__ uint32_t pretest_pk(uint32_t ip, uint32_t a, uint32_t
 }
 
 template <int R, bool WRITE_SCORES>
-__global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxTileMap tm, const uint8_t* __restrict__ pyr,
-                                                   OrbxFastParams fp, u64* __restrict__ mask,
-                                                   uint16_t* __restrict__ scores_dbg) {
+__global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxBandMap bm, int n_frames,
+                                                   const uint8_t* __restrict__ pyr, OrbxFastParams fp,
+                                                   u64* __restrict__ mask, uint16_t* __restrict__ scores_dbg,
+                                                   u64* __restrict__ row_stat) {
   constexpr int TH = ORBX_FAST_TH, TW = ORBX_FAST_TW;
   constexpr int IMG_ROWS = TH + 6 + 2 * R;
   constexpr int SC_ROWS = TH + 2 * R;
@@ -636,16 +554,37 @@ __global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxTileMap tm
   __shared__ uint16_t s_queue[SC_ROWS * F2_SC_PITCH];
   __shared__ __attribute__((aligned(8))) uint32_t s_mask32[TH * 2];
   __shared__ int s_qn;
+  __shared__ int s_skip;
 
-  int l, tx, ty;
-  decode_tile(tm, plan.nlevels, l, tx, ty);
+  int l, tx, ty, f;
+  decode_band(bm, plan.nlevels, n_frames, l, tx, ty, f);
   const OrbxLevel& L = plan.L[l];
-  const int f = blockIdx.y;
   const uint8_t* img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
   const int tid = threadIdx.x;
   const int thr = fp.threshold;
   const int x0 = tx * TW, y0 = ty * TH;
   const int gy0 = y0 - 3 - R;
+  u64* mrow = mask + (size_t)f * plan.mask_words + L.mask_off;
+  u64* stat = row_stat ? row_stat + ((size_t)f * ORBX_MAX_LEVELS + l) * ORBX_MAX_BANDS : nullptr;
+
+  // early exit: the tile rows above are complete and already hold >= cap survivors
+  if (stat && ty > 0) {
+    if (tid < 64) {
+      u64 st = 0;
+      if (tid < ty) st = __hip_atomic_load(&stat[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool complete = tid >= ty || (int)(st >> 32) == bm.tiles_x[l];
+      const u64 inc = __ballot(!complete);              // rows not yet complete
+      const int k = inc ? __ffsll((long long)inc) - 1 : 64;  // first incomplete row
+      const int surv = wave_sum(tid < k && tid < ty ? (int)(uint32_t)st : 0);
+      if (tid == 0) s_skip = surv >= L.cap;
+    }
+    __syncthreads();
+    if (s_skip) {
+      if (tid < TH && y0 + tid < L.h) mrow[(size_t)(y0 + tid) * L.mask_wpr + tx] = 0ull;
+      if (tid == 0) __hip_atomic_fetch_add(&stat[ty], 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
 
   // phase 1: tile + halo -> LDS with aligned 8-byte loads (x0-8 is 8-byte aligned)
   for (int i = tid; i < IMG_ROWS * (F2_IMG_DW / 2); i += 256) {
@@ -783,12 +722,18 @@ __global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxTileMap tm
   }
   __syncthreads();
 
-  // phase 5: one 8-byte store per tile row
+  // phase 5: one 8-byte store per tile row (TH == 64: exactly wave 0), and the
+  // tile's survivor count joins the tile-row statistics
   if (tid < TH) {
     const int gy = y0 + tid;
-    if (gy < L.h)
-      mask[(size_t)f * plan.mask_words + L.mask_off + (size_t)gy * L.mask_wpr + tx] =
-          reinterpret_cast<const u64*>(s_mask32)[tid];
+    const u64 word = reinterpret_cast<const u64*>(s_mask32)[tid];
+    if (gy < L.h) mrow[(size_t)gy * L.mask_wpr + tx] = word;
+    if (stat) {
+      const int surv = wave_sum(gy < L.h ? __popcll(word) : 0);
+      if (tid == 0)
+        __hip_atomic_fetch_add(&stat[ty], (1ull << 32) | (u64)(uint32_t)surv, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if (WRITE_SCORES) {
     for (int i = tid; i < TH * TW; i += 256) {
@@ -808,7 +753,7 @@ __global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxTileMap tm
 __global__ __launch_bounds__(256) void k_compact(OrbxPlan plan, const u64* __restrict__ mask,
                                                  orbx_keypoint* __restrict__ cand,
                                                  int32_t* __restrict__ cand_count,
-                                                 int32_t* __restrict__ cand_total) {
+                                                 int32_t* __restrict__ cand_total, int need_total) {
   __shared__ int s_wsum[4];
   const int l = blockIdx.x, f = blockIdx.y;
   const OrbxLevel& L = plan.L[l];
@@ -850,6 +795,9 @@ __global__ __launch_bounds__(256) void k_compact(OrbxPlan plan, const u64* __res
     }
     base += tot;
     __syncthreads();
+    // the cap is reached (block-uniform): later rows cannot contribute; `total`
+    // is then only a lower bound, which the whole-path callers never read
+    if (!need_total && base >= L.cap) break;
   }
   if (tid == 0) {
     cand_total[f * plan.nlevels + l] = base;
@@ -987,6 +935,7 @@ __global__ __launch_bounds__(256) void k_harris_flat(const uint8_t* __restrict__
 //    counting (response desc, index asc) -- a deterministic total order -- and
 //    scatter the first `quota` to the frame's result slots.  Levels are laid
 //    out back to back in level order (src/orb.cpp:100-102).
+#define SELECT_SLICES 4  // workgroups per (level, frame): each ranks a quarter of the candidates
 __global__ __launch_bounds__(256) void k_select(OrbxPlan plan, int mode, const orbx_keypoint* __restrict__ cand,
                                                 const int32_t* __restrict__ cand_count,
                                                 const float* __restrict__ resp,
@@ -994,13 +943,19 @@ __global__ __launch_bounds__(256) void k_select(OrbxPlan plan, int mode, const o
                                                 float* __restrict__ out_resp, int32_t* __restrict__ out_level,
                                                 int32_t* __restrict__ out_count) {
   __shared__ float s_r[ORBX_MAX_SELECT];
-  const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  const int l = blockIdx.x / SELECT_SLICES, slice = blockIdx.x - l * SELECT_SLICES;
+  const int f = blockIdx.y, tid = threadIdx.x;
   const OrbxLevel& L = plan.L[l];
-  const int n = cand_count[f * plan.nlevels + l];
+  // all level counts with ONE memory round trip (lanes 0..nlevels-1), then the
+  // output offset of this level = sum of the kept counts of the levels below
+  __shared__ int s_cnt[ORBX_MAX_LEVELS];
+  if (tid < plan.nlevels) s_cnt[tid] = cand_count[f * plan.nlevels + tid];
+  __syncthreads();
+  const int n = s_cnt[l];
   const int keep = n < L.quota ? n : L.quota;
   int out_off = 0;
   for (int i = 0; i < l; i++) {
-    const int c = cand_count[f * plan.nlevels + i];
+    const int c = s_cnt[i];
     out_off += c < plan.L[i].quota ? c : plan.L[i].quota;
   }
   const orbx_keypoint* ck = cand + (size_t)f * plan.cand_total + L.cand_off;
@@ -1009,7 +964,7 @@ __global__ __launch_bounds__(256) void k_select(OrbxPlan plan, int mode, const o
   float* orr = out_resp + (size_t)f * plan.out_cap + out_off;
   int32_t* ol = out_level + (size_t)f * plan.out_cap + out_off;
   if (mode == ORBX_SELECT_ROWMAJOR) {
-    for (int i = tid; i < keep; i += 256) {
+    for (int i = slice * 256 + tid; i < keep; i += 256 * SELECT_SLICES) {
       ok[i] = ck[i];
       orr[i] = 0.0f;
       ol[i] = l;
@@ -1017,7 +972,7 @@ __global__ __launch_bounds__(256) void k_select(OrbxPlan plan, int mode, const o
   } else {
     for (int i = tid; i < n; i += 256) s_r[i] = cr[i];
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
+    for (int i = slice * 256 + tid; i < n; i += 256 * SELECT_SLICES) {
       const float ri = s_r[i];
       int rank = 0;
       for (int j = 0; j < n; j++) {
@@ -1031,7 +986,7 @@ __global__ __launch_bounds__(256) void k_select(OrbxPlan plan, int mode, const o
       }
     }
   }
-  if (l == plan.nlevels - 1 && tid == 0) out_count[f] = out_off + keep;
+  if (l == plan.nlevels - 1 && slice == 0 && tid == 0) out_count[f] = out_off + keep;
 }
 
 __global__ __launch_bounds__(256) void k_select_flat(const float* __restrict__ resp, int n, int keep,
@@ -1276,6 +1231,252 @@ __global__ __launch_bounds__(256) void k_describe(OrbxPlan plan, const uint8_t* 
   }
 }
 
+// ---------------------------------------------------------------------------
+// 7b. orientation + BRIEF, second generation: a workgroup owns 16 keypoints.
+//   The per-keypoint transcendental work (restated atan2f, sinf, cosf: ~350
+//   instructions, identical in every lane of a wave-per-keypoint design) is
+//   done by 16 THREADS, one per keypoint, between two passes in which each
+//   wave serves its four keypoints:
+//     pass A  patch -> LDS, exact int32 moments (wave reduce)
+//     trig    thread j: angle_j, cos_j, sin_j
+//     pass C  patch -> LDS again (L1/L2 hit), separable 5x5 box table,
+//             256 rotated tests, 4 ballots
+//   Keypoints whose whole 41x41 neighbourhood is inside the image (wave-uniform
+//   test) skip the per-test bounds checks.
+#define DESC_KPW 4
+#define DESC_KPB (4 * DESC_KPW)
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS operations of one wave execute in order; this only pins the compiler
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#define DESC_NLD ((DESC_ROWS * (DESC_PITCH / 4) + 63) / 64)  // dwords per lane per patch (8)
+
+// global -> registers (all loads of a patch issued back to back; the caller
+// fetches the patches of ALL its keypoints before using the first one)
+__device__ __forceinline__ void desc_fetch_patch(const DescJob& jb, int lane, uint32_t (&regs)[DESC_NLD],
+                                                 int& off_out) {
+  const int px0 = jb.x - DESC_R, py0 = jb.y - DESC_R;
+  const int ax0 = px0 & ~3;
+  off_out = px0 - ax0;
+  int row = lane / (DESC_PITCH / 4), c = lane - row * (DESC_PITCH / 4);
+#pragma unroll
+  for (int k = 0; k < DESC_NLD; k++) {
+    const int gy = py0 + row, gx = ax0 + 4 * c;
+    uint32_t v = 0;
+    if (lane + 64 * k < DESC_ROWS * (DESC_PITCH / 4) && (unsigned)gy < (unsigned)jb.h &&
+        (unsigned)gx < (unsigned)jb.pitch)
+      v = *reinterpret_cast<const uint32_t*>(jb.img + (uint32_t)(gy * jb.pitch + gx));
+    regs[k] = v;
+    row += 5;
+    c += 4;
+    if (c >= DESC_PITCH / 4) {
+      c -= DESC_PITCH / 4;
+      row += 1;
+    }
+  }
+}
+
+__device__ __forceinline__ void desc_store_patch(DescLds& lds, int lane, const uint32_t (&regs)[DESC_NLD]) {
+#pragma unroll
+  for (int k = 0; k < DESC_NLD; k++)
+    if (lane + 64 * k < DESC_ROWS * (DESC_PITCH / 4)) lds.patch[lane + 64 * k] = regs[k];
+}
+
+__device__ __forceinline__ DescJob desc_job(const OrbxPlan& plan, const uint8_t* pyr, int f, orbx_keypoint kp,
+                                            int level) {
+  const OrbxLevel& L = plan.L[level];
+  DescJob jb;
+  jb.img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
+  jb.w = L.w;
+  jb.h = L.h;
+  jb.pitch = L.pitch;
+  jb.x = kp.x;
+  jb.y = kp.y;
+  jb.valid = true;
+  return jb;
+}
+
+__device__ __forceinline__ void desc_box_tables(DescLds& lds, int lane) {
+  {
+    int r = lane / 10, g = lane - r * 10;
+#pragma unroll
+    for (int k = 0; k < (DESC_ROWS * 10 + 63) / 64; k++) {
+      if (lane + 64 * k < DESC_ROWS * 10) {
+        const uint32_t d0 = lds.patch[r * (DESC_PITCH / 4) + g], d1 = lds.patch[r * (DESC_PITCH / 4) + g + 1];
+        const uint32_t b0 = d0 & 0xff, b1 = (d0 >> 8) & 0xff, b2 = (d0 >> 16) & 0xff, b3 = d0 >> 24;
+        const uint32_t b4 = d1 & 0xff, b5 = (d1 >> 8) & 0xff, b6 = (d1 >> 16) & 0xff, b7 = d1 >> 24;
+        const uint32_t s0 = b0 + b1 + b2 + b3 + b4;
+        const uint32_t s1 = s0 - b0 + b5, s2 = s1 - b1 + b6, s3 = s2 - b2 + b7;
+        *reinterpret_cast<uint2*>(&lds.hs[r * DESC_HP + 4 * g]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+      }
+      r += 6;
+      g += 4;
+      if (g >= 10) {
+        g -= 10;
+        r += 1;
+      }
+    }
+  }
+  wave_lds_sync();
+  {
+    int r = lane / 10, g = lane - r * 10;
+#pragma unroll
+    for (int k = 0; k < (DESC_BROWS * 10 + 63) / 64; k++) {
+      if (lane + 64 * k < DESC_BROWS * 10) {
+        const uint2* hp = reinterpret_cast<const uint2*>(&lds.hs[r * DESC_HP + 4 * g]);
+        uint2 acc = hp[0];
+#pragma unroll
+        for (int q = 1; q < 5; q++) {
+          const uint2 v = hp[q * (DESC_HP / 4)];
+          acc.x = pk_add(acc.x, v.x);
+          acc.y = pk_add(acc.y, v.y);
+        }
+        *reinterpret_cast<uint2*>(&lds.box[r * DESC_HP + 4 * g]) = acc;
+      }
+      r += 6;
+      g += 4;
+      if (g >= 10) {
+        g -= 10;
+        r += 1;
+      }
+    }
+  }
+  wave_lds_sync();
+}
+
+__global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t* __restrict__ pyr, int patch_size,
+                                                   const int32_t* __restrict__ out_count,
+                                                   const orbx_keypoint* __restrict__ out_lkp,
+                                                   const int32_t* __restrict__ out_level,
+                                                   orbx_keypoint* __restrict__ out_kp,
+                                                   float* __restrict__ out_angle,
+                                                   orbx_descriptor* __restrict__ out_desc) {
+  __shared__ __attribute__((aligned(16))) DescLds s_lds[4];
+  __shared__ int s_m[DESC_KPB][2];
+  __shared__ float s_cs[DESC_KPB][2];
+  const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int count = out_count[f];
+  const int slot0 = blockIdx.x * DESC_KPB;
+  if (slot0 >= count) return;  // whole workgroup
+  DescLds& lds = s_lds[wave];
+  const uint8_t* s_patch = reinterpret_cast<const uint8_t*>(lds.patch);
+  const size_t fo = (size_t)f * plan.out_cap;
+  const int pr = patch_size / 2, P = 2 * pr + 1;
+
+  // this wave's keypoints; all their patches are requested before the first is used
+  const int nk = min(DESC_KPW, max(0, count - (slot0 + wave * DESC_KPW)));  // wave-uniform
+  DescJob jobs[DESC_KPW];
+  float scale[DESC_KPW];
+  uint32_t regs[DESC_KPW][DESC_NLD];
+  int offs[DESC_KPW];
+#pragma unroll
+  for (int j = 0; j < DESC_KPW; j++) {
+    const int slot = min(slot0 + wave * DESC_KPW + j, count - 1);
+    const int level = out_level[fo + slot];
+    jobs[j] = desc_job(plan, pyr, f, out_lkp[fo + slot], level);
+    scale[j] = plan.L[level].scale;
+  }
+#pragma unroll
+  for (int j = 0; j < DESC_KPW; j++) desc_fetch_patch(jobs[j], lane, regs[j], offs[j]);
+
+  // pass A: moments
+#pragma unroll
+  for (int j = 0; j < DESC_KPW; j++) {
+    if (j < nk) {
+      const DescJob& jb = jobs[j];
+      const int q = wave * DESC_KPW + j, off = offs[j];
+      int m10 = 0, m01 = 0;
+      // full patch must lie inside the image, else angle 0 (src/orb_cpu.cpp:152-156)
+      if (!(jb.x - pr < 0 || jb.x + pr >= jb.w || jb.y - pr < 0 || jb.y + pr >= jb.h)) {
+        desc_store_patch(lds, lane, regs[j]);
+        wave_lds_sync();
+        const int grp_shift = P <= 32 ? 5 : 6;
+        const int col = lane & ((1 << grp_shift) - 1), grp = lane >> grp_shift, ngrp = 64 >> grp_shift;
+        int colsum = 0;
+        if (col < P) {
+          const uint8_t* pc = s_patch + (DESC_R - pr) * DESC_PITCH + (col - pr + DESC_R + off);
+#pragma unroll 4
+          for (int rr = grp; rr < P; rr += ngrp) {
+            const int I = pc[rr * DESC_PITCH];
+            colsum += I;
+            m01 += (rr - pr) * I;
+          }
+        }
+        m10 = wave_sum((col - pr) * colsum);
+        m01 = wave_sum(m01);
+        wave_lds_sync();
+      }
+      if (lane == 0) {
+        s_m[q][0] = m10;
+        s_m[q][1] = m01;
+      }
+    }
+  }
+  __syncthreads();
+  // trig: one thread per keypoint (moments are exact integers < 2^24, so the
+  // reference's float accumulation equals them; atan2f(0,0) = 0 covers the border case)
+  if (tid < DESC_KPB && slot0 + tid < count) {
+    const float angle = orbx_atan2f((float)s_m[tid][1], (float)s_m[tid][0]);
+    s_cs[tid][0] = orbx_cosf(angle);
+    s_cs[tid][1] = orbx_sinf(angle);
+    out_angle[fo + slot0 + tid] = angle;
+  }
+  __syncthreads();
+
+  // pass C: descriptors (the patches are still in registers)
+#pragma unroll
+  for (int j = 0; j < DESC_KPW; j++) {
+    if (j < nk) {
+      const DescJob& jb = jobs[j];
+      const int q = wave * DESC_KPW + j, slot = slot0 + q, off = offs[j];
+      desc_store_patch(lds, lane, regs[j]);
+      wave_lds_sync();
+      desc_box_tables(lds, lane);
+      const float c = s_cs[q][0], s = s_cs[q][1];
+      // every rotated centre is within 18 px of the keypoint; with a 20 px margin no test can be skipped
+      const bool interior = jb.x >= DESC_R && jb.y >= DESC_R && jb.x < jb.w - DESC_R && jb.y < jb.h - DESC_R;
+      u64 d[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int i = k * 64 + lane;
+        const int32_t pk = reinterpret_cast<const int32_t*>(c_pattern)[i];
+        const float x1 = (float)(int8_t)(pk & 0xff), y1 = (float)(int8_t)((pk >> 8) & 0xff);
+        const float x2 = (float)(int8_t)((pk >> 16) & 0xff), y2 = (float)(int8_t)((pk >> 24) & 0xff);
+        const int dx1 = orbx_lroundf(__fsub_rn(__fmul_rn(c, x1), __fmul_rn(s, y1)));
+        const int dy1 = orbx_lroundf(__fadd_rn(__fmul_rn(s, x1), __fmul_rn(c, y1)));
+        const int dx2 = orbx_lroundf(__fsub_rn(__fmul_rn(c, x2), __fmul_rn(s, y2)));
+        const int dy2 = orbx_lroundf(__fadd_rn(__fmul_rn(s, x2), __fmul_rn(c, y2)));
+        bool ok = true;
+        if (!interior) {
+          const int cx1 = jb.x + dx1, cy1 = jb.y + dy1, cx2 = jb.x + dx2, cy2 = jb.y + dy2;
+          ok = !(cx1 < 2 || cy1 < 2 || cx1 > jb.w - 1 || cy1 > jb.h - 1 || cx2 < 2 || cy2 < 2 || cx2 > jb.w - 1 ||
+                 cy2 > jb.h - 1);
+        }
+        const int s1 = lds.box[(dy1 + 18) * DESC_HP + dx1 + 18 + off];
+        const int s2 = lds.box[(dy2 + 18) * DESC_HP + dx2 + 18 + off];
+        d[k] = __ballot(ok && s1 < s2);
+      }
+      wave_lds_sync();
+      if (lane == 0) {
+        orbx_keypoint g;  // kp.x *= scale on int (src/orb.cpp:94-98)
+        g.x = (int)__fmul_rn((float)jb.x, scale[j]);
+        g.y = (int)__fmul_rn((float)jb.y, scale[j]);
+        out_kp[fo + slot] = g;
+        u64* dd = reinterpret_cast<u64*>(out_desc + fo + slot);
+        dd[0] = d[0];
+        dd[1] = d[1];
+        dd[2] = d[2];
+        dd[3] = d[3];
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_describe_flat(const uint8_t* __restrict__ img, int w, int h, int pitch,
                                                        const orbx_keypoint* __restrict__ kps, int nkp,
                                                        int patch_size, int use_given_angles, int do_brief,
@@ -1408,41 +1609,34 @@ hipError_t orbx_launch_blur2(hipStream_t s, const OrbxPlan& plan, const OrbxTile
 }
 
 template <int R>
-static void launch_fast2(dim3 grid, hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, const uint8_t* d_pyr,
-                         OrbxFastParams fp, unsigned long long* d_mask, uint16_t* d_scores_dbg) {
+static void launch_fast2(dim3 grid, hipStream_t s, const OrbxPlan& plan, const OrbxBandMap& bm, int n_frames,
+                         const uint8_t* d_pyr, OrbxFastParams fp, unsigned long long* d_mask,
+                         uint16_t* d_scores_dbg, unsigned long long* d_row_stat) {
   if (d_scores_dbg)
-    hipLaunchKernelGGL((k_fast_nms2<R, true>), grid, dim3(256), 0, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+    hipLaunchKernelGGL((k_fast_nms2<R, true>), grid, dim3(256), 0, s, plan, bm, n_frames, d_pyr, fp, d_mask,
+                       d_scores_dbg, d_row_stat);
   else
-    hipLaunchKernelGGL((k_fast_nms2<R, false>), grid, dim3(256), 0, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+    hipLaunchKernelGGL((k_fast_nms2<R, false>), grid, dim3(256), 0, s, plan, bm, n_frames, d_pyr, fp, d_mask,
+                       d_scores_dbg, d_row_stat);
 }
 
-hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
+// d_row_stat: n_frames * ORBX_MAX_LEVELS * ORBX_MAX_BANDS zeroed u64 (or NULL: no early exit)
+hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxPlan& plan, const OrbxBandMap& bm, int n_frames,
                                 const uint8_t* d_pyr, OrbxFastParams fp, unsigned long long* d_mask,
-                                uint16_t* d_scores_dbg) {
-  dim3 grid(tm.begin[plan.nlevels], n_frames);
-  static const int impl = [] {
-    const char* e = getenv("ORBX_FAST_IMPL");  // 1 = first-generation kernel (kept for A/B timing)
-    return e ? atoi(e) : 2;
-  }();
-  if (impl == 1) {
-    if (d_scores_dbg)
-      hipLaunchKernelGGL(k_fast_nms<true>, grid, dim3(256), 0, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
-    else
-      hipLaunchKernelGGL(k_fast_nms<false>, grid, dim3(256), 0, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
-    return ORBX_LAUNCH_CHECK();
-  }
+                                uint16_t* d_scores_dbg, unsigned long long* d_row_stat) {
+  dim3 grid(bm.band_begin[bm.nbands] * n_frames);
   switch (fp.nms_radius) {
     case 0:
-      launch_fast2<0>(grid, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+      launch_fast2<0>(grid, s, plan, bm, n_frames, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
       break;
     case 1:
-      launch_fast2<1>(grid, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+      launch_fast2<1>(grid, s, plan, bm, n_frames, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
       break;
     case 2:
-      launch_fast2<2>(grid, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+      launch_fast2<2>(grid, s, plan, bm, n_frames, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
       break;
     default:
-      launch_fast2<3>(grid, s, plan, tm, d_pyr, fp, d_mask, d_scores_dbg);
+      launch_fast2<3>(grid, s, plan, bm, n_frames, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
       break;
   }
   return ORBX_LAUNCH_CHECK();
@@ -1450,9 +1644,10 @@ hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxPlan& plan, const OrbxT
 
 hipError_t orbx_launch_compact(hipStream_t s, const OrbxPlan& plan, int n_frames,
                                const unsigned long long* d_mask, orbx_keypoint* d_cand, int32_t* d_cand_count,
-                               int32_t* d_cand_total) {
+                               int32_t* d_cand_total, int need_total) {
   dim3 grid(plan.nlevels, n_frames);
-  hipLaunchKernelGGL(k_compact, grid, dim3(256), 0, s, plan, d_mask, d_cand, d_cand_count, d_cand_total);
+  hipLaunchKernelGGL(k_compact, grid, dim3(256), 0, s, plan, d_mask, d_cand, d_cand_count, d_cand_total,
+                     need_total);
   return ORBX_LAUNCH_CHECK();
 }
 
@@ -1470,7 +1665,7 @@ hipError_t orbx_launch_select(hipStream_t s, const OrbxPlan& plan, int n_frames,
                               const orbx_keypoint* d_cand, const int32_t* d_cand_count, const float* d_resp,
                               orbx_keypoint* d_out_lkp, float* d_out_resp, int32_t* d_out_level,
                               int32_t* d_out_count) {
-  dim3 grid(plan.nlevels, n_frames);
+  dim3 grid(plan.nlevels * SELECT_SLICES, n_frames);
   hipLaunchKernelGGL(k_select, grid, dim3(256), 0, s, plan, mode, d_cand, d_cand_count, d_resp, d_out_lkp,
                      d_out_resp, d_out_level, d_out_count);
   return ORBX_LAUNCH_CHECK();
@@ -1481,9 +1676,19 @@ hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frame
                                 const int32_t* d_out_level, orbx_keypoint* d_out_kp, float* d_out_angle,
                                 orbx_descriptor* d_out_desc) {
   if (plan.out_cap <= 0) return hipSuccess;
-  dim3 grid((plan.out_cap + 3) / 4, n_frames);
-  hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_out_count, d_out_lkp,
-                     d_out_level, d_out_kp, d_out_angle, d_out_desc);
+  static const int impl = [] {
+    const char* e = getenv("ORBX_DESC_IMPL");  // 1 = first-generation kernel (A/B timing)
+    return e ? atoi(e) : 2;
+  }();
+  if (impl == 1) {
+    dim3 grid((plan.out_cap + 3) / 4, n_frames);
+    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_out_count, d_out_lkp,
+                       d_out_level, d_out_kp, d_out_angle, d_out_desc);
+  } else {
+    dim3 grid((plan.out_cap + DESC_KPB - 1) / DESC_KPB, n_frames);
+    hipLaunchKernelGGL(k_describe2, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_out_count, d_out_lkp,
+                       d_out_level, d_out_kp, d_out_angle, d_out_desc);
+  }
   return ORBX_LAUNCH_CHECK();
 }
 
