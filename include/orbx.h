@@ -153,6 +153,8 @@ int orbx_batch_fetch(orbx_ctx* ctx, int first, int n, int32_t* counts, orbx_keyp
 /* Per-stage device timings (ms) of the last batched call, in order:
  * pyramid, blur, fast+nms, compact, harris, select, orient+brief, total. */
 #define ORBX_NUM_STAGE_TIMES 8
+/* enable: 0 = off, 1 = events around every stage, 2 = only around the two
+ * roofline stages (blur, fast+nms; the other entries and `total` read 0). */
 int orbx_enable_stage_timing(orbx_ctx* ctx, int enable);
 int orbx_last_stage_times(orbx_ctx* ctx, float* ms);
 

@@ -95,9 +95,10 @@ struct orbx_ctx {
   // stage-API scratch (grown on demand; never touched by the batched path)
   DevBuf s_img_a, s_img_b, s_f32, s_u16, s_mask, s_kps, s_f32b, s_desc, s_i32, s_kern;
 
-  bool timing = false;
+  int timing = 0;  // 0 off, 1 all stages, 2 blur + fast only
   hipEvent_t ev[ORBX_NUM_STAGE_TIMES + 1] = {};
   bool ev_valid = false;
+  int ev_mode = 0;
   float last_ms[ORBX_NUM_STAGE_TIMES] = {};
 };
 
@@ -255,7 +256,7 @@ int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string
 // (imgproc/src/resize.cpp: scale = 1/((double)dst/src); fx = (float)((dx+0.5)*
 // scale-0.5); sx = floor(fx); clamp with fx=0; 11-bit coefficients by cvRound).
 // OpenCV is not part of this image: PARITY UNPINNED (DESIGN.md "Pyramid").
-void make_taps(const OrbxPlan& plan, std::vector<OrbxResizeTap>* taps) {
+void make_taps(OrbxPlan& plan, std::vector<OrbxResizeTap>* taps) {
   size_t total = 0;
   for (int l = 1; l < plan.nlevels; l++) total += (size_t)align_up(plan.L[l].w, 4) + align_up(plan.L[l].h, 4);
   taps->assign(total ? total : 1, OrbxResizeTap{0, 0, 0});
@@ -285,6 +286,16 @@ void make_taps(const OrbxPlan& plan, std::vector<OrbxResizeTap>* taps) {
         t.c1 = t.c0;
         t.c0 = 0;
       }
+    }
+    // can k_pyramid2 fetch the pairs of outputs 4g..4g+3 with one 8-byte window?
+    {
+      bool ok = plan.w0 >= 8;
+      for (int dx = 0; dx + 3 < L.w && ok; dx += 4)
+        ok = (*taps)[L.xtab_off + dx + 3].ofs + 1 - (*taps)[L.xtab_off + dx].ofs <= 7;
+      // (a trailing partial group only adds padding taps with ofs 0, which the kernel never uses)
+      for (int dx = L.w & ~3; dx < L.w && ok; dx++)
+        ok = (*taps)[L.xtab_off + dx].ofs + 1 - (*taps)[L.xtab_off + (L.w & ~3)].ofs <= 7;
+      plan.L[l].win8 = ok ? 1 : 0;
     }
     for (int dy = 0; dy < L.h; dy++) {
       float fy = (float)((dy + 0.5) * scale_y - 0.5);
@@ -421,39 +432,45 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   int st = set_plan(c, w, h);
   if (st != ORBX_OK) return st;
   const OrbxPlan& P = c->plan;
-  const bool t = c->timing;
-  int e = 0;
-  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  const int tm = c->timing;
+  // event slots: 0 start | 1 pyramid | 2 blur | 3 fast | 4 compact | 5 harris | 6 select | 7 describe
+  auto mark = [&](int slot, bool roofline_edge) -> hipError_t {
+    if (tm == 1 || (tm == 2 && roofline_edge)) return hipEventRecord(c->ev[slot], s);
+    return hipSuccess;
+  };
+  HIPCHK(c, mark(0, false));
   HIPCHK(c, launch_pyramid_auto(c, s, n, d_frames, row_stride, frame_stride));
-  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  HIPCHK(c, mark(1, true));
   if (blur_enabled(c))
     HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->tm_blur2, n, c->d_pyr, c->d_pyr_blur,
                                c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
-  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  HIPCHK(c, mark(2, true));
   OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2, fast_ablate()};
   HIPCHK(c, launch_fast_whole(c, s, n, fp));
-  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  HIPCHK(c, mark(3, true));
   HIPCHK(c, orbx_launch_compact(s, P, n, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total, 0));
-  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  HIPCHK(c, mark(4, false));
   if (c->p.select_mode == ORBX_SELECT_HARRIS)
     HIPCHK(c, orbx_launch_harris(s, P, n, final_pyr(c), c->d_cand, c->d_cand_count, c->d_gauss,
                                  c->p.harris_window, c->p.harris_k, c->d_resp));
-  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  HIPCHK(c, mark(5, false));
   // result block sections are laid out for (n, pool slot capacity)
   c->out_layout = make_out_layout(n, P.out_cap > 0 ? P.out_cap : 1);
   const OutLayout& o = c->out_layout;
   HIPCHK(c, orbx_launch_select(s, P, n, c->p.select_mode, c->d_cand, c->d_cand_count, c->d_resp,
                                (orbx_keypoint*)(c->d_out + o.lkp), (float*)(c->d_out + o.resp),
                                (int32_t*)(c->d_out + o.level), (int32_t*)(c->d_out + o.counts)));
-  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  HIPCHK(c, mark(6, false));
   HIPCHK(c, orbx_launch_describe(s, P, n, final_pyr(c), c->p.patch_size, (const int32_t*)(c->d_out + o.counts),
                                  (const orbx_keypoint*)(c->d_out + o.lkp), (const int32_t*)(c->d_out + o.level),
                                  (orbx_keypoint*)(c->d_out + o.kp), (float*)(c->d_out + o.angle),
                                  (orbx_descriptor*)(c->d_out + o.desc)));
-  if (t) HIPCHK(c, hipEventRecord(c->ev[e++], s));
+  HIPCHK(c, mark(7, false));
+  const int t = tm;
   c->last_n = n;
   c->last_stream = s;
-  c->ev_valid = t;
+  c->ev_valid = t != 0;
+  c->ev_mode = t;
   return ORBX_OK;
 }
 
@@ -716,9 +733,16 @@ int orbx_wait(orbx_ctx* c) {
   if (!c) return ORBX_ERR_INVALID_ARG;
   HIPCHK(c, hipStreamSynchronize(c->last_stream ? c->last_stream : c->stream));
   if (c->ev_valid) {
-    for (int i = 0; i < ORBX_NUM_STAGE_TIMES - 1; i++)
-      HIPCHK(c, hipEventElapsedTime(&c->last_ms[i], c->ev[i], c->ev[i + 1]));
-    HIPCHK(c, hipEventElapsedTime(&c->last_ms[ORBX_NUM_STAGE_TIMES - 1], c->ev[0], c->ev[ORBX_NUM_STAGE_TIMES - 1]));
+    std::memset(c->last_ms, 0, sizeof(c->last_ms));
+    if (c->ev_mode == 1) {
+      for (int i = 0; i < ORBX_NUM_STAGE_TIMES - 1; i++)
+        HIPCHK(c, hipEventElapsedTime(&c->last_ms[i], c->ev[i], c->ev[i + 1]));
+      HIPCHK(c, hipEventElapsedTime(&c->last_ms[ORBX_NUM_STAGE_TIMES - 1], c->ev[0],
+                                    c->ev[ORBX_NUM_STAGE_TIMES - 1]));
+    } else {  // blur and fast+nms only
+      HIPCHK(c, hipEventElapsedTime(&c->last_ms[1], c->ev[1], c->ev[2]));
+      HIPCHK(c, hipEventElapsedTime(&c->last_ms[2], c->ev[2], c->ev[3]));
+    }
     c->ev_valid = false;
   }
   return ORBX_OK;
@@ -726,7 +750,7 @@ int orbx_wait(orbx_ctx* c) {
 
 int orbx_enable_stage_timing(orbx_ctx* c, int enable) {
   if (!c) return ORBX_ERR_INVALID_ARG;
-  c->timing = enable != 0;
+  c->timing = enable < 0 || enable > 2 ? 1 : enable;
   return ORBX_OK;
 }
 

@@ -26,6 +26,7 @@ struct OrbxLevel {
   int32_t xtab_off;  // first entry of this level's resize x-table
   int32_t ytab_off;  // first entry of this level's resize y-table
   float scale;       // (float)pow(scaleFactor, l)  src/orb.cpp:95
+  int32_t win8;      // resize: the 4 source pairs of any aligned group of 4 outputs fit one 8-byte window
 };
 
 struct OrbxPlan {
@@ -82,7 +83,7 @@ int orbx_blur2_rows_per_wave();  // 16 or 32; tile height of k_blur2 = 4x this
 #define ORBX_PYR2_TW 256
 #define ORBX_PYR2_TH 16
 
-#define ORBX_MAX_SELECT 8192  // largest per-level FAST cap the select kernel ranks in LDS
+#define ORBX_MAX_SELECT 8192  // largest per-level FAST cap the select kernel ranks in LDS (8 B per candidate)
 
 // ---- launchers (orbx_kernels.hip) ------------------------------------------
 // All take the stream explicitly and never synchronise or allocate.

@@ -128,6 +128,10 @@ __global__ __launch_bounds__(256) void k_pyramid(OrbxPlan plan, OrbxTileMap tm, 
 //     reused for four rows; all 32 pixel-pair gathers of a lane are issued
 //     before the first is consumed.
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+struct __attribute__((packed, aligned(1))) uint2_unaligned {
+  uint32_t x, y;
+  __device__ operator uint2() const { return make_uint2(x, y); }
+};
 #define PYR2_ROWS 4  // output rows per wave
 
 __global__ __launch_bounds__(256) void k_pyramid2(OrbxPlan plan, OrbxTileMap tm, const uint8_t* __restrict__ in,
@@ -180,20 +184,49 @@ __global__ __launch_bounds__(256) void k_pyramid2(OrbxPlan plan, OrbxTileMap tm,
   // gather phase: 2 source rows x 4 pixel pairs x 4 output rows
   uint32_t p0[PYR2_ROWS][4], p1[PYR2_ROWS][4];
   int b0[PYR2_ROWS], b1[PYR2_ROWS];
-#pragma unroll
-  for (int r = 0; r < PYR2_ROWS; r++) {
-    const int y = min(yb + r, L.h - 1);  // rows past the level repeat the last one (not stored)
-    const OrbxResizeTap ty_ = taps[L.ytab_off + y];  // wave-uniform -> scalar load
-    const int sy0 = min(max(ty_.ofs, 0), plan.h0 - 1), sy1 = min(max(ty_.ofs + 1, 0), plan.h0 - 1);
-    const uint8_t* S0 = src + (size_t)sy0 * in_stride;
-    const uint8_t* S1 = src + (size_t)sy1 * in_stride;
-    b0[r] = ty_.c0;
-    b1[r] = ty_.c1;
+  if (L.win8) {
+    // Levels with scale <= 2: the four source pairs of a lane lie inside one
+    // 8-byte window (host-verified per level), so ONE unaligned 8-byte load per
+    // source row replaces four 2-byte gathers; v_perm picks each pair out of it.
+    // The window start is clamped so that it never reads past the source row.
+    const uint32_t base = min(ofs[0], (uint32_t)(plan.w0 - 8));
+    uint32_t sel[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      // ofs <= w0-2 always (host table): one unaligned 16-bit load fetches src[ofs], src[ofs+1]
-      p0[r][k] = *reinterpret_cast<const u16_unaligned*>(S0 + ofs[k]);
-      p1[r][k] = *reinterpret_cast<const u16_unaligned*>(S1 + ofs[k]);
+      const uint32_t sb = ofs[k] - base;  // 0..6
+      sel[k] = 0x0c0c0000u | ((sb + 1) << 8) | sb;
+    }
+#pragma unroll
+    for (int r = 0; r < PYR2_ROWS; r++) {
+      const int y = min(yb + r, L.h - 1);
+      const OrbxResizeTap ty_ = taps[L.ytab_off + y];
+      const int sy0 = min(max(ty_.ofs, 0), plan.h0 - 1), sy1 = min(max(ty_.ofs + 1, 0), plan.h0 - 1);
+      const uint2 w0v = *reinterpret_cast<const uint2_unaligned*>(src + (size_t)sy0 * in_stride + base);
+      const uint2 w1v = *reinterpret_cast<const uint2_unaligned*>(src + (size_t)sy1 * in_stride + base);
+      b0[r] = ty_.c0;
+      b1[r] = ty_.c1;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        p0[r][k] = __builtin_amdgcn_perm(w0v.y, w0v.x, sel[k]);
+        p1[r][k] = __builtin_amdgcn_perm(w1v.y, w1v.x, sel[k]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < PYR2_ROWS; r++) {
+      const int y = min(yb + r, L.h - 1);  // rows past the level repeat the last one (not stored)
+      const OrbxResizeTap ty_ = taps[L.ytab_off + y];  // wave-uniform -> scalar load
+      const int sy0 = min(max(ty_.ofs, 0), plan.h0 - 1), sy1 = min(max(ty_.ofs + 1, 0), plan.h0 - 1);
+      const uint8_t* S0 = src + (size_t)sy0 * in_stride;
+      const uint8_t* S1 = src + (size_t)sy1 * in_stride;
+      b0[r] = ty_.c0;
+      b1[r] = ty_.c1;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        // ofs <= w0-2 always (host table): one unaligned 16-bit load fetches src[ofs], src[ofs+1]
+        p0[r][k] = *reinterpret_cast<const u16_unaligned*>(S0 + ofs[k]);
+        p1[r][k] = *reinterpret_cast<const u16_unaligned*>(S1 + ofs[k]);
+      }
     }
   }
   int c0[4], c1[4];
@@ -942,9 +975,12 @@ __global__ __launch_bounds__(256) void k_select(OrbxPlan plan, int mode, const o
                                                 orbx_keypoint* __restrict__ out_lkp,
                                                 float* __restrict__ out_resp, int32_t* __restrict__ out_level,
                                                 int32_t* __restrict__ out_count) {
-  __shared__ float s_r[ORBX_MAX_SELECT];
+  extern __shared__ __attribute__((aligned(16))) float s_r[];  // max per-level cap, rounded up to 4
   const int l = blockIdx.x / SELECT_SLICES, slice = blockIdx.x - l * SELECT_SLICES;
   const int f = blockIdx.y, tid = threadIdx.x;
+  const int abl = mode >> 4;  // timing diagnostics only
+  mode &= 15;
+  if (abl & 8) return;
   const OrbxLevel& L = plan.L[l];
   // all level counts with ONE memory round trip (lanes 0..nlevels-1), then the
   // output offset of this level = sum of the kept counts of the levels below
@@ -954,10 +990,12 @@ __global__ __launch_bounds__(256) void k_select(OrbxPlan plan, int mode, const o
   const int n = s_cnt[l];
   const int keep = n < L.quota ? n : L.quota;
   int out_off = 0;
+  if (!(abl & 2))
   for (int i = 0; i < l; i++) {
     const int c = s_cnt[i];
     out_off += c < plan.L[i].quota ? c : plan.L[i].quota;
   }
+  if (abl & 4) return;
   const orbx_keypoint* ck = cand + (size_t)f * plan.cand_total + L.cand_off;
   const float* cr = resp + (size_t)f * plan.cand_total + L.cand_off;
   orbx_keypoint* ok = out_lkp + (size_t)f * plan.out_cap + out_off;
@@ -970,14 +1008,33 @@ __global__ __launch_bounds__(256) void k_select(OrbxPlan plan, int mode, const o
       ol[i] = l;
     }
   } else {
-    for (int i = tid; i < n; i += 256) s_r[i] = cr[i];
+    // Total order (response desc, index asc) as ONE unsigned 64-bit key per
+    // candidate: high word = order-preserving image of the float (-0 folded into
+    // +0 so that equal floats give equal words), low word = ~index.  Ranking is
+    // then one 64-bit compare + one add-with-carry per pair instead of three
+    // compares and two mask ops.
+    u64* s_key = reinterpret_cast<u64*>(s_r);
+    const int n2 = (n + 1) & ~1;
+    for (int i = tid; i < n2; i += 256) {
+      u64 k = 0ull;  // padding: the smallest key, never outranks anything
+      if (i < n) {
+        uint32_t u = orbx_f2u(cr[i]);
+        if (u == 0x80000000u) u = 0u;
+        u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+        k = ((u64)u << 32) | (uint32_t)~(uint32_t)i;
+      }
+      s_key[i] = k;
+    }
     __syncthreads();
     for (int i = slice * 256 + tid; i < n; i += 256 * SELECT_SLICES) {
-      const float ri = s_r[i];
+      const u64 ki = s_key[i];
+      const float ri = cr[i];
       int rank = 0;
-      for (int j = 0; j < n; j++) {
-        const float rj = s_r[j];
-        rank += (rj > ri) || (rj == ri && j < i);
+#pragma unroll 4
+      for (int j = 0; j < ((abl & 1) ? 0 : n2); j += 2) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&s_key[j]);
+        rank += v.x > ki;
+        rank += v.y > ki;
       }
       if (rank < keep) {
         ok[rank] = ck[i];
@@ -1666,7 +1723,12 @@ hipError_t orbx_launch_select(hipStream_t s, const OrbxPlan& plan, int n_frames,
                               orbx_keypoint* d_out_lkp, float* d_out_resp, int32_t* d_out_level,
                               int32_t* d_out_count) {
   dim3 grid(plan.nlevels * SELECT_SLICES, n_frames);
-  hipLaunchKernelGGL(k_select, grid, dim3(256), 0, s, plan, mode, d_cand, d_cand_count, d_resp, d_out_lkp,
+  int maxcap = 4;
+  for (int l = 0; l < plan.nlevels; l++) maxcap = plan.L[l].cap > maxcap ? plan.L[l].cap : maxcap;
+  const size_t lds = (size_t)((maxcap + 3) & ~3) * sizeof(unsigned long long);
+  static const int abl = [] { const char* e = getenv("ORBX_SELECT_ABLATE"); return e ? atoi(e) : 0; }();
+  mode |= abl << 4;
+  hipLaunchKernelGGL(k_select, grid, dim3(256), lds, s, plan, mode, d_cand, d_cand_count, d_resp, d_out_lkp,
                      d_out_resp, d_out_level, d_out_count);
   return ORBX_LAUNCH_CHECK();
 }

@@ -244,8 +244,9 @@ class Context:
         return dict(counts=counts, kps=kps, kps_level=lkp, angles=ang, responses=resp, levels=lev, desc=desc,
                     status=st)
 
-    def enable_stage_timing(self, on=True):
-        self._chk(self._lib.orbx_enable_stage_timing(self._h, 1 if on else 0))
+    def enable_stage_timing(self, mode=1):
+        """0/False off, 1/True events around every stage, 2 only around blur and fast+nms."""
+        self._chk(self._lib.orbx_enable_stage_timing(self._h, int(mode)))
 
     def last_stage_times(self):
         ms = np.zeros(NUM_STAGE_TIMES, np.float32)
