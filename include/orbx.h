@@ -158,6 +158,12 @@ int orbx_batch_fetch(orbx_ctx* ctx, int first, int n, int32_t* counts, orbx_keyp
 int orbx_enable_stage_timing(orbx_ctx* ctx, int enable);
 int orbx_last_stage_times(orbx_ctx* ctx, float* ms);
 
+/* FAST/NMS tiles that provably cannot contribute to the first `cap` row-major
+ * survivors exit early in the batched path (results are identical either way;
+ * DESIGN.md "Early exit").  enable = 0 makes every tile do the full work (used
+ * to measure the kernel's full-work throughput).  Default: enabled. */
+int orbx_set_fast_early_exit(orbx_ctx* ctx, int enable);
+
 /* Runs only the blur + FAST/NMS stages of the last-built pyramid `reps` times
  * (the roofline kernels) and reports the average duration of
  * each, measured with HIP events on the context's stream. */

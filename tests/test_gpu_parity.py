@@ -285,3 +285,31 @@ def test_error_paths(pkg):
         pkg.Context(pkg.default_params("gpu", n=17))
     with pytest.raises(pkg.OrbxError):  # level 15 of a 64x64 frame is < 8x8
         pkg.Context(pkg.default_params("gpu", nlevels=16, max_width=64, max_height=64))
+
+
+def test_fast_early_exit_is_invisible(pkg, kitti0, kitti1):
+    """Tiles that provably cannot reach the first `cap` row-major survivors exit early in the
+    batched path; outputs must be identical with the early exit on and off, and equal the oracle."""
+    frames = np.stack([kitti0, kitti1, np.roll(kitti1, (7, 3), (0, 1)), kitti0[::-1].copy()])
+    p = pkg.default_params("gpu", nfeatures=600, max_width=1241, max_height=376, max_batch=4, blur_levels=2)
+    with pkg.Context(p) as c:
+        cap = c.plan(1241, 376)["out_capacity"]
+        c.set_fast_early_exit(True)
+        c.batch_host(frames)
+        a = c.batch_fetch(0, 4, cap)
+        c.set_fast_early_exit(False)
+        c.batch_host(frames)
+        b = c.batch_fetch(0, 4, cap)
+        for k in ("counts", "kps", "kps_level", "angles", "desc", "levels", "responses"):
+            assert np.array_equal(a[k], b[k]), k
+    ref = O.detect_and_compute_gpu(frames[3], O.gpu_params(nfeatures=600, blur_levels=2))
+    n = int(a["counts"][3])
+    assert n == len(ref["kps"]) and np.array_equal(a["kps"][3, :n], ref["kps"])
+    # CPU flavour: the row-major cap (3000 at threshold 20 is hit at row 174) is exact under early exit
+    p = pkg.default_params("cpu", threshold=20, max_width=1241, max_height=376, max_batch=2)
+    with pkg.Context(p) as c:
+        c.batch_host(np.stack([kitti0, kitti1]))
+        r = c.batch_fetch(0, 2, 3000)
+    kps, ang, desc, valid = O.detect_and_compute_cpu(kitti0, threshold=20)
+    assert r["counts"][0] == 3000 == len(kps) and np.array_equal(r["kps"][0], kps)
+    assert np.array_equal(r["desc"][0] & valid, desc & valid)

@@ -96,6 +96,7 @@ struct orbx_ctx {
   DevBuf s_img_a, s_img_b, s_f32, s_u16, s_mask, s_kps, s_f32b, s_desc, s_i32, s_kern;
 
   int timing = 0;  // 0 off, 1 all stages, 2 blur + fast only
+  int fast_early = 1;
   hipEvent_t ev[ORBX_NUM_STAGE_TIMES + 1] = {};
   bool ev_valid = false;
   int ev_mode = 0;
@@ -400,12 +401,12 @@ const uint8_t* final_pyr(const orbx_ctx* c);
 // first `cap` row-major survivors exit early (see decode_band in the kernels);
 // ORBX_FAST_EARLY=0 disables that (every tile does the full work).
 hipError_t launch_fast_whole(orbx_ctx* c, hipStream_t s, int n, OrbxFastParams fp) {
-  static const int early = [] {
+  static const int early_env = [] {
     const char* e = getenv("ORBX_FAST_EARLY");
     return e ? atoi(e) : 1;
   }();
   unsigned long long* stat = nullptr;
-  if (early) {
+  if (early_env && c->fast_early) {
     stat = c->d_row_stat;
     hipError_t e = hipMemsetAsync(stat, 0, (size_t)n * ORBX_MAX_LEVELS * ORBX_MAX_BANDS * 8, s);
     if (e != hipSuccess) return e;
@@ -421,6 +422,14 @@ hipError_t launch_blur_auto(hipStream_t s, const OrbxPlan& P, const OrbxTileMap&
     const char* e = getenv("ORBX_BLUR_IMPL");
     return e ? atoi(e) : 2;
   }();
+  // ORBX_BLUR_COPY_ALL=1: every level takes the pass-through copy path (known byte
+  // count with this kernel's 4-byte-per-lane access pattern; used to calibrate the
+  // FETCH_SIZE / WRITE_SIZE counters, results are of course not blurred)
+  static const int copy_all = [] {
+    const char* e = getenv("ORBX_BLUR_COPY_ALL");
+    return e ? atoi(e) : 0;
+  }();
+  if (copy_all) first_level = ORBX_MAX_LEVELS;
   if (kind == ORBX_BLUR_SEP16 && impl != 1) return orbx_launch_blur2(s, P, tm2, n, src, dst, first_level);
   return orbx_launch_blur(s, P, tm1, n, src, dst, first_level, kind);
 }
@@ -745,6 +754,12 @@ int orbx_wait(orbx_ctx* c) {
     }
     c->ev_valid = false;
   }
+  return ORBX_OK;
+}
+
+int orbx_set_fast_early_exit(orbx_ctx* c, int enable) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  c->fast_early = enable != 0;
   return ORBX_OK;
 }
 

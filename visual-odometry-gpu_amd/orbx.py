@@ -28,7 +28,7 @@ EXPORTS = [
     "orbx_last_error_string", "orbx_status_string", "orbx_version", "orbx_get_plan",
     "orbx_detect_and_compute", "orbx_detect_and_compute_batch_device", "orbx_detect_and_compute_batch_host",
     "orbx_wait", "orbx_batch_results_device", "orbx_batch_fetch", "orbx_enable_stage_timing",
-    "orbx_last_stage_times", "orbx_bench_stage", "orbx_fast_score", "orbx_nms", "orbx_fast",
+    "orbx_last_stage_times", "orbx_bench_stage", "orbx_set_fast_early_exit", "orbx_fast_score", "orbx_nms", "orbx_fast",
     "orbx_orientations", "orbx_brief", "orbx_harris", "orbx_blur5_sep", "orbx_blur5_273", "orbx_conv2d",
     "orbx_gaussian_blur_conv", "orbx_gaussian_kernel", "orbx_sobel", "orbx_build_pyramid_level",
     "orbx_select_top",
@@ -247,6 +247,9 @@ class Context:
     def enable_stage_timing(self, mode=1):
         """0/False off, 1/True events around every stage, 2 only around blur and fast+nms."""
         self._chk(self._lib.orbx_enable_stage_timing(self._h, int(mode)))
+
+    def set_fast_early_exit(self, on=True):
+        self._chk(self._lib.orbx_set_fast_early_exit(self._h, 1 if on else 0))
 
     def last_stage_times(self):
         ms = np.zeros(NUM_STAGE_TIMES, np.float32)
