@@ -313,3 +313,65 @@ def test_fast_early_exit_is_invisible(pkg, kitti0, kitti1):
     kps, ang, desc, valid = O.detect_and_compute_cpu(kitti0, threshold=20)
     assert r["counts"][0] == 3000 == len(kps) and np.array_equal(r["kps"][0], kps)
     assert np.array_equal(r["desc"][0] & valid, desc & valid)
+
+
+@pytest.mark.parametrize("w", [8, 9, 10, 11, 63, 64, 65, 243, 244, 245, 246, 247, 248, 249, 250, 251, 252, 253, 255, 256,
+                               257, 492, 495, 496, 497, 500, 744, 745])
+def test_blur_width_sweep(ctx, w):
+    """k_blur2 strip / lane boundaries: the dword holding the last pixel falls on every lane position
+    (incl. the halo lanes 0 and 63 of a 248-pixel strip) and every byte position."""
+    for h in (8, 17, 64, 65):
+        img = synth(w * 131 + h, h, w, "noise")
+        assert np.array_equal(ctx.blur5_sep(img), O.blur5_sep(img)), (w, h)
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (65, 65), (127, 129), (128, 128), (129, 127), (70, 200), (200, 70),
+                                   (191, 255), (193, 257)])
+def test_whole_path_tile_boundaries(pkg, shape):
+    """Frame sizes around the 64x64 FAST tiles, the 256x16 pyramid tiles and the 8-byte resize
+    windows (right-edge clamp), multi-level, Harris selection, blur on."""
+    h, w = shape
+    img = synth(h * 7 + w, h, w)
+    kw = dict(nfeatures=400, nlevels=4, blur_levels=2)
+    p = pkg.default_params("gpu", max_width=w, max_height=h, **kw)
+    op = O.gpu_params(**kw)
+    with pkg.Context(p) as c:
+        for l in range(4):
+            assert np.array_equal(c.build_pyramid_level(img, l), O.build_level(img, op, l)), (shape, l)
+        check_whole(c.detect_and_compute(img), O.detect_and_compute_gpu(img, op))
+
+
+def test_scale_factors_and_resize_paths(pkg, kitti1):
+    """scale factors on both sides of the 8-byte-window limit (scale <= 2 per level)."""
+    img = np.ascontiguousarray(kitti1[:300, :1000])
+    for sf, nl in ((1.1, 6), (1.5, 5), (2.0, 4), (2.5, 3), (3.0, 3)):
+        kw = dict(nfeatures=500, nlevels=nl, scale_factor=sf)
+        p = pkg.default_params("gpu", max_width=1000, max_height=300, **kw)
+        op = O.gpu_params(**kw)
+        with pkg.Context(p) as c:
+            for l in range(nl):
+                assert np.array_equal(c.build_pyramid_level(img, l), O.build_level(img, op, l)), (sf, l)
+            check_whole(c.detect_and_compute(img), O.detect_and_compute_gpu(img, op))
+
+
+def test_random_frames_many(pkg):
+    """A few hundred keypoint-rich random frames through the batched path vs the oracle (rare-event hunting:
+    rounding ties in the rotation, ties in NMS and in the Harris ranking)."""
+    kw = dict(nfeatures=800, nlevels=5, threshold=12, blur_levels=2)
+    h, w = 120, 200
+    p = pkg.default_params("gpu", max_width=w, max_height=h, max_batch=32, **kw)
+    op = O.gpu_params(**kw)
+    with pkg.Context(p) as c:
+        cap = c.plan(w, h)["out_capacity"]
+        for rnd in range(4):
+            frames = np.stack([synth(1000 * rnd + i, h, w, "rects" if i % 3 else "noise") for i in range(32)])
+            c.batch_host(frames)
+            r = c.batch_fetch(0, 32, cap)
+            for i in range(32):
+                ref = O.detect_and_compute_gpu(frames[i], op)
+                n = int(r["counts"][i])
+                got = dict(count=n, kps=r["kps"][i, :n], kps_level=r["kps_level"][i, :n], levels=r["levels"][i, :n],
+                           angles=r["angles"][i, :n], responses=r["responses"][i, :n], desc=r["desc"][i, :n])
+                check_whole(got, ref)
+                assert np.array_equal(got["angles"].view(np.uint32), ref["angles"].view(np.uint32))
+                assert np.array_equal(got["responses"].view(np.uint32), ref["responses"].view(np.uint32))

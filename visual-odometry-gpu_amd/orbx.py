@@ -151,6 +151,10 @@ class Context:
         if st != OK:
             raise OrbxError(st, self._lib.orbx_last_error_string(None).decode())
         self._h = h
+        self._cap_cache = {}
+        self._dac = self._lib.orbx_detect_and_compute
+        self._dac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [
+            C.c_int, C.POINTER(C.c_int)]
 
     def close(self):
         if getattr(self, "_h", None):
@@ -193,17 +197,20 @@ class Context:
         image = _img(image)
         h, w = image.shape
         if capacity is None:
-            capacity = max(self.plan(w, h)["out_capacity"], 1)
-        kps = np.zeros((capacity, 2), np.int32)
-        lkp = np.zeros((capacity, 2), np.int32)
-        ang = np.zeros(capacity, np.float32)
-        resp = np.zeros(capacity, np.float32)
-        lev = np.zeros(capacity, np.int32)
-        desc = np.zeros((capacity, 32), np.uint8)
+            capacity = self._cap_cache.get((w, h))
+            if capacity is None:
+                capacity = self._cap_cache[(w, h)] = max(self.plan(w, h)["out_capacity"], 1)
+        kps = np.empty((capacity, 2), np.int32)
+        lkp = np.empty((capacity, 2), np.int32)
+        ang = np.empty(capacity, np.float32)
+        resp = np.empty(capacity, np.float32)
+        lev = np.empty(capacity, np.int32)
+        desc = np.empty((capacity, 32), np.uint8)
         cnt = C.c_int(0)
-        st = self._lib.orbx_detect_and_compute(self._h, _ptr(image), w, h, image.strides[0], _ptr(kps), _ptr(ang),
-                                               _ptr(desc), _ptr(resp), _ptr(lev), _ptr(lkp), capacity, C.byref(cnt))
-        self._chk(st, allow=(ERR_CAPACITY,))
+        st = self._dac(self._h, image.ctypes.data, w, h, image.strides[0], kps.ctypes.data, ang.ctypes.data,
+                       desc.ctypes.data, resp.ctypes.data, lev.ctypes.data, lkp.ctypes.data, capacity, C.byref(cnt))
+        if st != OK and st != ERR_CAPACITY:
+            self._chk(st)
         c = min(cnt.value, capacity)
         return dict(count=cnt.value, status=st, kps=kps[:c], kps_level=lkp[:c], angles=ang[:c], responses=resp[:c],
                     levels=lev[:c], desc=desc[:c])
