@@ -157,6 +157,11 @@ int orbx_batch_fetch(orbx_ctx* ctx, int first, int n, int32_t* counts, orbx_keyp
  * roofline stages (blur, fast+nms; the other entries and `total` read 0). */
 int orbx_enable_stage_timing(orbx_ctx* ctx, int enable);
 int orbx_last_stage_times(orbx_ctx* ctx, float* ms);
+/* Same for the timed batched call `back` calls ago (0 = the last one; up to
+ * ORBX_EVENT_SETS-1): several timed calls may be enqueued back to back and read
+ * after one orbx_wait(), so timing adds no host synchronisation between steps. */
+#define ORBX_EVENT_SETS 64
+int orbx_stage_times_history(orbx_ctx* ctx, int back, float* ms);
 
 /* FAST/NMS tiles that provably cannot contribute to the first `cap` row-major
  * survivors exit early in the batched path (results are identical either way;

@@ -97,10 +97,12 @@ struct orbx_ctx {
 
   int timing = 0;  // 0 off, 1 all stages, 2 blur + fast only
   int fast_early = 1;
-  hipEvent_t ev[ORBX_NUM_STAGE_TIMES + 1] = {};
-  bool ev_valid = false;
-  int ev_mode = 0;
-  float last_ms[ORBX_NUM_STAGE_TIMES] = {};
+  // ring of event sets: one per timed batched call, so that several calls can be
+  // in flight before their stage times are read (no host sync between steps)
+  hipEvent_t evr[ORBX_EVENT_SETS][ORBX_NUM_STAGE_TIMES + 1] = {};
+  int ev_mode[ORBX_EVENT_SETS] = {};
+  long long ev_calls = 0;  // timed batched calls so far
+  hipEvent_t ev[2] = {};   // orbx_bench_stage
 };
 
 namespace {
@@ -442,9 +444,10 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   if (st != ORBX_OK) return st;
   const OrbxPlan& P = c->plan;
   const int tm = c->timing;
+  hipEvent_t* evs = c->evr[c->ev_calls % ORBX_EVENT_SETS];
   // event slots: 0 start | 1 pyramid | 2 blur | 3 fast | 4 compact | 5 harris | 6 select | 7 describe
   auto mark = [&](int slot, bool roofline_edge) -> hipError_t {
-    if (tm == 1 || (tm == 2 && roofline_edge)) return hipEventRecord(c->ev[slot], s);
+    if (tm == 1 || (tm == 2 && roofline_edge)) return hipEventRecord(evs[slot], s);
     return hipSuccess;
   };
   HIPCHK(c, mark(0, false));
@@ -478,8 +481,10 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   const int t = tm;
   c->last_n = n;
   c->last_stream = s;
-  c->ev_valid = t != 0;
-  c->ev_mode = t;
+  if (t != 0) {
+    c->ev_mode[c->ev_calls % ORBX_EVENT_SETS] = t;
+    c->ev_calls++;
+  }
   return ORBX_OK;
 }
 
@@ -602,6 +607,9 @@ void orbx_destroy(orbx_ctx* c) {
     if (b->p) (void)hipFree(b->p);
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& set : c->evr)
+    for (auto& e : set)
+      if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -654,6 +662,8 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
 
   CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (auto& e : c->ev) CREATE_CHK(hipEventCreate(&e));
+  for (auto& set : c->evr)
+    for (auto& e : set) CREATE_CHK(hipEventCreate(&e));
   CREATE_CHK(hipMalloc((void**)&c->d_in, B * (size_t)p->max_width * p->max_height + 256));
   CREATE_CHK(hipMalloc((void**)&c->d_pyr, B * (size_t)M.frame_bytes + 256));
   if (p->blur_levels != ORBX_BLUR_NONE)
@@ -741,19 +751,6 @@ int orbx_detect_and_compute_batch_host(orbx_ctx* c, const uint8_t* frames, int n
 int orbx_wait(orbx_ctx* c) {
   if (!c) return ORBX_ERR_INVALID_ARG;
   HIPCHK(c, hipStreamSynchronize(c->last_stream ? c->last_stream : c->stream));
-  if (c->ev_valid) {
-    std::memset(c->last_ms, 0, sizeof(c->last_ms));
-    if (c->ev_mode == 1) {
-      for (int i = 0; i < ORBX_NUM_STAGE_TIMES - 1; i++)
-        HIPCHK(c, hipEventElapsedTime(&c->last_ms[i], c->ev[i], c->ev[i + 1]));
-      HIPCHK(c, hipEventElapsedTime(&c->last_ms[ORBX_NUM_STAGE_TIMES - 1], c->ev[0],
-                                    c->ev[ORBX_NUM_STAGE_TIMES - 1]));
-    } else {  // blur and fast+nms only
-      HIPCHK(c, hipEventElapsedTime(&c->last_ms[1], c->ev[1], c->ev[2]));
-      HIPCHK(c, hipEventElapsedTime(&c->last_ms[2], c->ev[2], c->ev[3]));
-    }
-    c->ev_valid = false;
-  }
   return ORBX_OK;
 }
 
@@ -769,11 +766,25 @@ int orbx_enable_stage_timing(orbx_ctx* c, int enable) {
   return ORBX_OK;
 }
 
-int orbx_last_stage_times(orbx_ctx* c, float* ms) {
+int orbx_stage_times_history(orbx_ctx* c, int back, float* ms) {
   if (!c || !ms) return ORBX_ERR_INVALID_ARG;
-  std::memcpy(ms, c->last_ms, sizeof(c->last_ms));
+  if (back < 0 || back >= ORBX_EVENT_SETS || back >= c->ev_calls)
+    return fail(c, ORBX_ERR_INVALID_ARG, "no timed batched call that far back");
+  const long long call = c->ev_calls - 1 - back;
+  hipEvent_t* evs = c->evr[call % ORBX_EVENT_SETS];
+  const int mode = c->ev_mode[call % ORBX_EVENT_SETS];
+  std::memset(ms, 0, sizeof(float) * ORBX_NUM_STAGE_TIMES);
+  if (mode == 1) {
+    for (int i = 0; i < ORBX_NUM_STAGE_TIMES - 1; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], evs[i], evs[i + 1]));
+    HIPCHK(c, hipEventElapsedTime(&ms[ORBX_NUM_STAGE_TIMES - 1], evs[0], evs[ORBX_NUM_STAGE_TIMES - 1]));
+  } else {  // blur and fast+nms only
+    HIPCHK(c, hipEventElapsedTime(&ms[1], evs[1], evs[2]));
+    HIPCHK(c, hipEventElapsedTime(&ms[2], evs[2], evs[3]));
+  }
   return ORBX_OK;
 }
+
+int orbx_last_stage_times(orbx_ctx* c, float* ms) { return orbx_stage_times_history(c, 0, ms); }
 
 int orbx_batch_results_device(orbx_ctx* c, orbx_batch_view* v) {
   if (!c || !v) return ORBX_ERR_INVALID_ARG;

@@ -28,7 +28,7 @@ EXPORTS = [
     "orbx_last_error_string", "orbx_status_string", "orbx_version", "orbx_get_plan",
     "orbx_detect_and_compute", "orbx_detect_and_compute_batch_device", "orbx_detect_and_compute_batch_host",
     "orbx_wait", "orbx_batch_results_device", "orbx_batch_fetch", "orbx_enable_stage_timing",
-    "orbx_last_stage_times", "orbx_bench_stage", "orbx_set_fast_early_exit", "orbx_fast_score", "orbx_nms", "orbx_fast",
+    "orbx_last_stage_times", "orbx_stage_times_history", "orbx_bench_stage", "orbx_set_fast_early_exit", "orbx_fast_score", "orbx_nms", "orbx_fast",
     "orbx_orientations", "orbx_brief", "orbx_harris", "orbx_blur5_sep", "orbx_blur5_273", "orbx_conv2d",
     "orbx_gaussian_blur_conv", "orbx_gaussian_kernel", "orbx_sobel", "orbx_build_pyramid_level",
     "orbx_select_top",
@@ -258,9 +258,10 @@ class Context:
     def set_fast_early_exit(self, on=True):
         self._chk(self._lib.orbx_set_fast_early_exit(self._h, 1 if on else 0))
 
-    def last_stage_times(self):
+    def last_stage_times(self, back=0):
+        """Stage times (ms) of the timed batched call `back` calls ago; call wait() first."""
         ms = np.zeros(NUM_STAGE_TIMES, np.float32)
-        self._chk(self._lib.orbx_last_stage_times(self._h, _ptr(ms)))
+        self._chk(self._lib.orbx_stage_times_history(self._h, back, _ptr(ms)))
         return dict(zip(STAGE_NAMES, ms.tolist()))
 
     def bench_stage(self, n_frames, stage, reps):
