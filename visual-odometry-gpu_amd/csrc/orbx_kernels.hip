@@ -935,6 +935,139 @@ __device__ __forceinline__ float harris_any(const uint8_t* img, int w, int h, in
   return harris_at(img, w, h, pitch, x, y, g, K, kk);
 }
 
+// Eight lanes per keypoint (second generation): lane r of a group computes window
+// row r -- three patch rows, the Sobel sums and the 3 x K weighted products of that
+// row -- in parallel with its neighbours; the float accumulators then travel
+// lane 0 -> 1 -> ... -> K-1 (DPP row_shr:1), each lane adding its K products in
+// order, which reproduces the oracle's (i,j) row-major summation bit for bit.
+// 8x more waves than thread-per-keypoint (the old kernel had 2 waves per SIMD)
+// and a ~6x shorter dependent chain per keypoint.
+template <int K>
+__device__ __forceinline__ float harris_row_group(const uint8_t* img, int pitch, int x, int y,
+                                                  const float* __restrict__ g, float kk, int sub) {
+  constexpr int r = K / 2, P = K + 2;
+  const int row_i = sub < K ? sub : K - 1;  // idle lanes shadow the last row (their sums are never used)
+  const int xs = x - r - 1;
+  const int a0 = xs & ~3, off = xs - a0;
+  float p[3][P];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(img + (size_t)(y - r - 1 + row_i + i) * pitch + a0);
+    const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];
+    const uint32_t q[3] = {__builtin_amdgcn_alignbyte(d1, d0, off), __builtin_amdgcn_alignbyte(d2, d1, off),
+                           d2 >> (8 * off)};
+#pragma unroll
+    for (int j = 0; j < P; j++) p[i][j] = (float)((q[j >> 2] >> (8 * (j & 3))) & 0xffu);
+  }
+  float pa[K], pb[K], pc[K];
+  {
+    float vs[P], h0[K], h2[K];
+#pragma unroll
+    for (int j = 0; j < P; j++) vs[j] = p[0][j] + 2.0f * p[1][j] + p[2][j];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      h0[j] = p[0][j] + 2.0f * p[0][j + 1] + p[0][j + 2];
+      h2[j] = p[2][j] + 2.0f * p[2][j + 1] + p[2][j + 2];
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const float gx = vs[j + 2] - vs[j], gy = h2[j] - h0[j];
+      const float wgt = g[row_i * K + j];
+      pa[j] = __fmul_rn(__fmul_rn(gx, gx), wgt);
+      pc[j] = __fmul_rn(__fmul_rn(gy, gy), wgt);
+      pb[j] = __fmul_rn(__fmul_rn(gx, gy), wgt);
+    }
+  }
+  float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+  for (int rr = 0; rr < K; rr++) {
+    if (sub == rr) {
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        a = __fadd_rn(a, pa[j]);
+        c = __fadd_rn(c, pc[j]);
+        b = __fadd_rn(b, pb[j]);
+      }
+    }
+    if (rr + 1 < K) {  // hand the running sums to the next lane of the group
+      const float an = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x111, 0xf, 0xf, true));
+      const float bn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x111, 0xf, 0xf, true));
+      const float cn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), 0x111, 0xf, 0xf, true));
+      if (sub == rr + 1) {
+        a = an;
+        b = bn;
+        c = cn;
+      }
+    }
+  }
+  const float det = __fsub_rn(__fmul_rn(a, c), __fmul_rn(b, b));
+  const float trace = __fadd_rn(a, c);
+  return __fsub_rn(det, __fmul_rn(__fmul_rn(kk, trace), trace));  // valid in lane sub == K-1
+}
+
+// one keypoint per 8-lane group; result returned in every lane of the group's
+// lane `K-1` (fast path) or lane 0 (generic path); `writer` tells which
+__device__ __forceinline__ float harris_group(const uint8_t* img, int w, int h, int pitch, int x, int y,
+                                              const float* __restrict__ g, int K, float kk, int sub, bool active,
+                                              bool& writer) {
+  const int m = K / 2 + 1;
+  const bool fast = (K == 7 || K == 5 || K == 3) && x >= m && y >= m && x < w - m && y < h - m;
+  float res = 0.f;
+  writer = false;
+  // the fast path is taken group-wise but executed wave-wide (DPP needs all lanes of the row active)
+  const bool any_fast = __any(active && fast);
+  if (any_fast) {
+    const int xx = (active && fast) ? x : m, yy = (active && fast) ? y : m;  // harmless in-image stand-in
+    float v = 0.f;
+    if (K == 7) v = harris_row_group<7>(img, pitch, xx, yy, g, kk, sub);
+    else if (K == 5) v = harris_row_group<5>(img, pitch, xx, yy, g, kk, sub);
+    else v = harris_row_group<3>(img, pitch, xx, yy, g, kk, sub);
+    if (active && fast && sub == K - 1) {
+      res = v;
+      writer = true;
+    }
+  }
+  if (active && !fast && sub == 0) {
+    res = harris_at(img, w, h, pitch, x, y, g, K, kk);
+    writer = true;
+  }
+  return res;
+}
+
+__global__ __launch_bounds__(256) void k_harris2(OrbxPlan plan, const uint8_t* __restrict__ pyr,
+                                                 const orbx_keypoint* __restrict__ cand,
+                                                 const int32_t* __restrict__ cand_count,
+                                                 const float* __restrict__ gauss, int K, float kk,
+                                                 float* __restrict__ resp) {
+  const int j = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+  const int f = blockIdx.y;
+  int l = 0;
+  for (int i = 1; i < plan.nlevels; i++)
+    if (j >= plan.L[i].cand_off) l = i;
+  const OrbxLevel& L = plan.L[l];
+  const bool active = j < plan.cand_total && (j - L.cand_off) < cand_count[f * plan.nlevels + l];
+  orbx_keypoint kp = {4, 4};
+  if (active) kp = cand[(size_t)f * plan.cand_total + j];
+  // lanes of one wave may sit on different levels: the level image is per lane
+  const uint8_t* img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
+  bool writer;
+  const float v = harris_group(img, L.w, L.h, L.pitch, kp.x, kp.y, gauss, K, kk, sub, active, writer);
+  if (writer) resp[(size_t)f * plan.cand_total + j] = v;
+}
+
+__global__ __launch_bounds__(256) void k_harris2_flat(const uint8_t* __restrict__ img, int w, int h, int pitch,
+                                                      const orbx_keypoint* __restrict__ kps, int nkp,
+                                                      const float* __restrict__ gauss, int K, float kk,
+                                                      float* __restrict__ resp) {
+  const int j = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+  const bool active = j < nkp;
+  orbx_keypoint kp = {4, 4};
+  if (active) kp = kps[j];
+  bool writer;
+  const float v = harris_group(img, w, h, pitch, kp.x, kp.y, gauss, K, kk, sub, active, writer);
+  if (writer) resp[j] = v;
+}
+
 __global__ __launch_bounds__(256) void k_harris(OrbxPlan plan, const uint8_t* __restrict__ pyr,
                                                 const orbx_keypoint* __restrict__ cand,
                                                 const int32_t* __restrict__ cand_count,
@@ -1712,9 +1845,23 @@ hipError_t orbx_launch_harris(hipStream_t s, const OrbxPlan& plan, int n_frames,
                               const orbx_keypoint* d_cand, const int32_t* d_cand_count, const float* d_gauss,
                               int window, float k, float* d_resp) {
   if (plan.cand_total <= 0) return hipSuccess;
-  dim3 grid((plan.cand_total + 255) / 256, n_frames);
-  hipLaunchKernelGGL(k_harris, grid, dim3(256), 0, s, plan, d_pyr, d_cand, d_cand_count, d_gauss, window, k,
-                     d_resp);
+  static const int impl = [] {
+    const char* e = getenv("ORBX_HARRIS_IMPL");  // 1 = thread-per-keypoint kernel (A/B timing)
+    return e ? atoi(e) : 2;  // 3 = always the 8-lane kernel
+  }();
+  // thread-per-keypoint does less total work and wins once there are enough keypoints
+  // to fill the chip (34 vs 44 us at 64 frames); the 8-lane kernel has the shorter
+  // critical path and wins for a few frames (22 vs 27 us at one frame)
+  const bool many = (long long)plan.cand_total * n_frames >= 16384;
+  if (impl == 1 || (impl == 2 && many)) {
+    dim3 grid((plan.cand_total + 255) / 256, n_frames);
+    hipLaunchKernelGGL(k_harris, grid, dim3(256), 0, s, plan, d_pyr, d_cand, d_cand_count, d_gauss, window, k,
+                       d_resp);
+  } else {
+    dim3 grid((plan.cand_total + 31) / 32, n_frames);
+    hipLaunchKernelGGL(k_harris2, grid, dim3(256), 0, s, plan, d_pyr, d_cand, d_cand_count, d_gauss, window, k,
+                       d_resp);
+  }
   return ORBX_LAUNCH_CHECK();
 }
 
@@ -1767,7 +1914,7 @@ hipError_t orbx_launch_harris_flat(hipStream_t s, const uint8_t* d_img, int w, i
                                    const orbx_keypoint* d_kps, int nkp, const float* d_gauss, int K, float kk,
                                    float* d_resp) {
   if (nkp <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_harris_flat, dim3((nkp + 255) / 256), dim3(256), 0, s, d_img, w, h, pitch, d_kps, nkp,
+  hipLaunchKernelGGL(k_harris2_flat, dim3((nkp + 31) / 32), dim3(256), 0, s, d_img, w, h, pitch, d_kps, nkp,
                      d_gauss, K, kk, d_resp);
   return ORBX_LAUNCH_CHECK();
 }
