@@ -375,3 +375,16 @@ def test_random_frames_many(pkg):
                 check_whole(got, ref)
                 assert np.array_equal(got["angles"].view(np.uint32), ref["angles"].view(np.uint32))
                 assert np.array_equal(got["responses"].view(np.uint32), ref["responses"].view(np.uint32))
+
+
+def test_fast_candidate_queue_overflow(ctx):
+    """More than F2_QCAP (2048) pre-test survivors in one 64x64 tile: the queue-less path."""
+    img = synth(5, 130, 200, "noise")
+    for t in (1, 2, 5):
+        ref, npre, _ = O.fast_score(img, t, 9)
+        assert npre > 3 * 2048  # really overflows (several tiles)
+        assert np.array_equal(ctx.fast_score(img, t, 9), ref), t
+        s, _, _ = O.fast_score(img, t, 9)
+        kr, tot = O.nms(s, 3, 100000)
+        kg, gtot = ctx.fast(img, t, 9, 3, 100000)
+        assert gtot == tot and np.array_equal(kg, kr)

@@ -555,6 +555,10 @@ static_assert(ORBX_FAST_TH == 64, "phase 5 assumes one wave per tile column of m
 #define F2_IMG_DW (F2_IMG_PITCH / 4)    // 20
 #define F2_SC_PITCH 72                  // score tile columns: x0-4 .. x0+67
 #define F2_DCOLS (F2_SC_PITCH / 4)      // 18 dword columns per score row
+// candidate queue capacity.  A tile has up to 72*70 candidates but natural images give
+// ~300; a bounded queue keeps LDS at 20 KB (8 workgroups per CU).  Tiles with more
+// candidates (noise, tiny thresholds) take a slower, queue-less path.
+#define F2_QCAP 2048
 
 // pre-test of the two pixels held in the 16-bit lanes of the arguments;
 // returns bit15 / bit31 set for candidates
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxBandMap bm
   constexpr int N_ITEMS = SC_ROWS * F2_DCOLS;
   __shared__ __attribute__((aligned(16))) uint32_t s_img32[IMG_ROWS * F2_IMG_DW];
   __shared__ __attribute__((aligned(16))) uint16_t s_score[SC_ROWS * F2_SC_PITCH];
-  __shared__ uint16_t s_queue[SC_ROWS * F2_SC_PITCH];
+  __shared__ uint16_t s_queue[F2_QCAP];
   __shared__ __attribute__((aligned(8))) uint32_t s_mask32[TH * 2];
   __shared__ int s_qn;
   __shared__ int s_skip;
@@ -685,6 +689,7 @@ __global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxBandMap bm
     }
     if (fp.ablate & 1) cand_bits = 0;  // diagnostics: no candidates -> phases 3/4 are empty
   }
+  const uint32_t my_cands = cand_bits;  // kept for the queue-less overflow path
   {
     const int lane = tid & 63;
     const int cnt = __popc(cand_bits);
@@ -703,16 +708,18 @@ __global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxBandMap bm
       cand_bits &= cand_bits - 1;
       const int i = tid + 256 * (bpos >> 2);
       const int isy = i / F2_DCOLS, idc = i - isy * F2_DCOLS;
-      s_queue[pos++] = (uint16_t)(isy * F2_SC_PITCH + 4 * idc + (bpos & 3));
+      if (pos < F2_QCAP) s_queue[pos] = (uint16_t)(isy * F2_SC_PITCH + 4 * idc + (bpos & 3));
+      pos++;
     }
   }
   __syncthreads();
 
   // phase 3: full segment test + score on the compacted candidates (src/orb_cpu.cpp:61-101)
   const uint8_t* s_img = reinterpret_cast<const uint8_t*>(s_img32);
-  const int nq = s_qn;
-  for (int q = tid; q < nq; q += 256) {
-    const int pos = s_queue[q];
+  const int ntot = s_qn;
+  const bool overflow = ntot > F2_QCAP;  // block-uniform
+  const int nq = overflow ? 0 : ntot;
+  auto score_candidate = [&](int pos) {
     const int sy = pos / F2_SC_PITCH, sx = pos - sy * F2_SC_PITCH;
     const uint8_t* p = s_img + (sy + 3) * F2_IMG_PITCH + (sx + 4);
     const int Ip = p[0], hi = Ip + thr, lo = Ip - thr;
@@ -722,23 +729,31 @@ __global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxBandMap bm
                           p[3 * F2_IMG_PITCH - 1],  p[2 * F2_IMG_PITCH - 2],  p[F2_IMG_PITCH - 3],
                           p[-3],                    p[-F2_IMG_PITCH - 3],     p[-2 * F2_IMG_PITCH - 2],
                           p[-3 * F2_IMG_PITCH - 1]};
-    uint32_t bm = 0, dm = 0;
+    uint32_t bmk = 0, dmk = 0;
     int score = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int v = ring[k];
-      bm |= (uint32_t)(v >= hi) << k;
-      dm |= (uint32_t)(v <= lo) << k;
+      bmk |= (uint32_t)(v >= hi) << k;
+      dmk |= (uint32_t)(v <= lo) << k;
       score += abs(Ip - v);
     }
-    if (has_run16(bm, fp.n) || has_run16(dm, fp.n)) s_score[pos] = (uint16_t)score;
-  }
+    if (has_run16(bmk, fp.n) || has_run16(dmk, fp.n)) s_score[pos] = (uint16_t)score;
+  };
+  // position of candidate bit `bpos` of this thread (same mapping as the compaction above)
+  auto bit_pos = [&](int bpos) {
+    const int i = tid + 256 * (bpos >> 2);
+    const int isy = i / F2_DCOLS, idc = i - isy * F2_DCOLS;
+    return isy * F2_SC_PITCH + 4 * idc + (bpos & 3);
+  };
+  for (int q = tid; q < nq; q += 256) score_candidate(s_queue[q]);
+  if (overflow)
+    for (uint32_t b = my_cands; b; b &= b - 1) score_candidate(bit_pos(__ffs(b) - 1));
   __syncthreads();
 
   // phase 4: NMS, corners only (ties survive, src/orb_cpu.cpp:110-133); survivors
   // of the tile interior set their bit in the LDS mask
-  for (int q = tid; q < ((fp.ablate & 4) ? 0 : nq); q += 256) {
-    const int pos = s_queue[q];
+  auto nms_candidate = [&](int pos) {
     const int s = s_score[pos];
     if (s > 0) {
       const int sy = pos / F2_SC_PITCH, sx = pos - sy * F2_SC_PITCH;
@@ -752,6 +767,11 @@ __global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxBandMap bm
         if (keep) atomicOr(&s_mask32[iy * 2 + (ix >> 5)], 1u << (ix & 31));
       }
     }
+  };
+  if (!(fp.ablate & 4)) {
+    for (int q = tid; q < nq; q += 256) nms_candidate(s_queue[q]);
+    if (overflow)
+      for (uint32_t b = my_cands; b; b &= b - 1) nms_candidate(bit_pos(__ffs(b) - 1));
   }
   __syncthreads();
 
