@@ -56,10 +56,15 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return p >= len ? len - 1 : p;
 }
 
+// wave-wide integer sum, result in every lane.  DPP within the 16-lane rows
+// (no LDS-crossbar round trips), then the four row sums are combined on the SALU.
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E /*quad_perm:[2,3,0,1]*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141 /*row_half_mirror*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140 /*row_mirror*/, 0xf, 0xf, true);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
 }
 
 // ---------------------------------------------------------------------------
@@ -623,14 +628,25 @@ __global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxBandMap bm
     }
   }
 
-  // phase 1: tile + halo -> LDS with aligned 8-byte loads (x0-8 is 8-byte aligned)
-  for (int i = tid; i < IMG_ROWS * (F2_IMG_DW / 2); i += 256) {
-    const int row = i / (F2_IMG_DW / 2), c = i - row * (F2_IMG_DW / 2);
-    const int gy = gy0 + row, gx = x0 - 8 + 8 * c;
-    uint2 v = make_uint2(0u, 0u);
-    if (gy >= 0 && gy < L.h && gx >= 0 && gx + 8 <= L.pitch)
-      v = *reinterpret_cast<const uint2*>(img + (size_t)gy * L.pitch + gx);
-    reinterpret_cast<uint2*>(s_img32)[i] = v;
+  // phase 1: tile + halo -> LDS with aligned 8-byte loads (x0-8 is 8-byte aligned).
+  // All loads of a thread are issued before the first is stored (one memory latency
+  // per tile instead of one per loop iteration).
+  {
+    constexpr int NLOADS = IMG_ROWS * (F2_IMG_DW / 2), NPT = (NLOADS + 255) / 256;
+    uint2 v[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; k++) {
+      const int i = tid + 256 * k;
+      const int row = i / (F2_IMG_DW / 2), c = i - row * (F2_IMG_DW / 2);
+      const int gy = gy0 + row, gx = x0 - 8 + 8 * c;
+      v[k] = make_uint2(0u, 0u);
+      // gx, pitch are multiples of 8: (unsigned)gx < pitch  <=>  0 <= gx && gx + 8 <= pitch
+      if (i < NLOADS && (unsigned)gy < (unsigned)L.h && (unsigned)gx < (unsigned)L.pitch)
+        v[k] = *reinterpret_cast<const uint2*>(img + (uint32_t)(gy * L.pitch + gx));
+    }
+#pragma unroll
+    for (int k = 0; k < NPT; k++)
+      if (tid + 256 * k < NLOADS) reinterpret_cast<uint2*>(s_img32)[tid + 256 * k] = v[k];
   }
   for (int i = tid; i < SC_ROWS * F2_SC_PITCH / 8; i += 256)
     reinterpret_cast<uint4*>(s_score)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1231,9 +1247,13 @@ __global__ __launch_bounds__(256) void k_select_flat(const float* __restrict__ r
 
 // per-wavefront LDS working set
 struct DescLds {
-  uint32_t patch[DESC_ROWS * DESC_PITCH / 4];  // 41 x 48 u8
-  uint16_t hs[DESC_ROWS * DESC_HP];            // horizontal 5-sums: hs[r][j] = sum patch[r][j..j+4]
-  uint16_t box[DESC_BROWS * DESC_HP];          // 5x5 sums: box[r][j] = sum hs[r..r+4][j]
+  // the patch is dead once the horizontal sums exist, so the 5x5 table reuses its
+  // space (6.2 KB per wave -> 6 workgroups per CU instead of 4)
+  union {
+    uint32_t patch[DESC_ROWS * DESC_PITCH / 4];  // 41 x 48 u8
+    uint16_t box[DESC_BROWS * DESC_HP];          // 5x5 sums: box[r][j] = sum hs[r..r+4][j]
+  };
+  uint16_t hs[DESC_ROWS * DESC_HP];  // horizontal 5-sums: hs[r][j] = sum patch[r][j..j+4]
 };
 
 struct DescJob {
