@@ -251,6 +251,30 @@ int orbx_build_pyramid_level(orbx_ctx* ctx, const uint8_t* image, int width, int
  * responses ordered by (response desc, index asc). */
 int orbx_select_top(orbx_ctx* ctx, const float* responses, int n, int keep, int32_t* indices, int* kept);
 
+/* ---- next row: descriptor matching ------------------ */
+
+/* flann->knnMatch(des1, des2, matches, 2) (src/feature_matching.cpp:166-168,
+ * src/feature_tracking.cpp:203-204) as an EXACT brute-force Hamming 2-NN search
+ * (the reference's FLANN LSH index is approximate).  idx/dist: nq x 2 (best,
+ * second best; -1 when the train set has fewer descriptors); ties keep the lower
+ * train index. */
+int orbx_knn2(orbx_ctx* ctx, const orbx_descriptor* query, int nq, const orbx_descriptor* train, int nt,
+              int32_t* idx, int32_t* dist);
+
+/* knnMatch + the ratio test `m.distance < ratio * n.distance`
+ * (src/feature_matching.cpp:172-181; ratio = 0.8 there), matches in query order.
+ * dist1 may be NULL.  *count = number of matches; ORBX_ERR_CAPACITY if > capacity. */
+int orbx_match_ratio(orbx_ctx* ctx, const orbx_descriptor* query, int nq, const orbx_descriptor* train, int nt,
+                     double ratio, int32_t* query_idx, int32_t* train_idx, int32_t* dist1, int capacity, int* count);
+
+/* Device-resident: matches frame i (query) against frame i+1 (train) for every
+ * consecutive pair of the last batch -- the VO loop's get_matches() shape -- on
+ * the batch's stream, straight from the result slots (no host round trip). */
+int orbx_batch_match_consecutive(orbx_ctx* ctx, double ratio);
+/* matches of pair `pair` (frames pair, pair+1) of the last orbx_batch_match_consecutive. */
+int orbx_batch_match_fetch(orbx_ctx* ctx, int pair, int32_t* query_idx, int32_t* train_idx, int32_t* dist1,
+                           int capacity, int* count);
+
 #ifdef __cplusplus
 }
 #endif

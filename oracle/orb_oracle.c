@@ -552,3 +552,55 @@ int oracle_detect_and_compute_gpu(const uint8_t* img, int w, int h, int stride, 
   }
   return total;
 }
+
+/* ------------------------------------------------------------------------ */
+/* descriptor matching (next row)                      */
+
+static int hamming256(const uint8_t* a, const uint8_t* b) {
+  int d = 0;
+  for (int i = 0; i < 32; i++) d += __builtin_popcount((unsigned)(a[i] ^ b[i]));
+  return d;
+}
+
+void oracle_knn2(const uint8_t* query, int nq, const uint8_t* train, int nt, int32_t* idx, int32_t* dist) {
+  for (int i = 0; i < nq; i++) {
+    int d1 = 1 << 30, d2 = 1 << 30, j1 = -1, j2 = -1;
+    for (int j = 0; j < nt; j++) {
+      const int d = hamming256(query + (size_t)i * 32, train + (size_t)j * 32);
+      if (d < d1) {
+        d2 = d1;
+        j2 = j1;
+        d1 = d;
+        j1 = j;
+      } else if (d < d2) {
+        d2 = d;
+        j2 = j;
+      }
+    }
+    idx[2 * i] = j1;
+    idx[2 * i + 1] = j2;
+    dist[2 * i] = j1 >= 0 ? d1 : -1;
+    dist[2 * i + 1] = j2 >= 0 ? d2 : -1;
+  }
+}
+
+int oracle_match_ratio(const uint8_t* query, int nq, const uint8_t* train, int nt, double ratio,
+                       int32_t* query_idx, int32_t* train_idx, int32_t* dist1) {
+  int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(nq > 0 ? nq : 1));
+  int32_t* dist = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(nq > 0 ? nq : 1));
+  oracle_knn2(query, nq, train, nt, idx, dist);
+  int n = 0;
+  for (int i = 0; i < nq; i++) {
+    if (idx[2 * i + 1] < 0) continue; /* matches[i].size() < 2  (feature_matching.cpp:174) */
+    const float m = (float)dist[2 * i], nn = (float)dist[2 * i + 1]; /* DMatch::distance is float */
+    if (m < ratio * nn) { /* :177 */
+      query_idx[n] = i;
+      train_idx[n] = idx[2 * i];
+      if (dist1) dist1[n] = dist[2 * i];
+      n++;
+    }
+  }
+  free(idx);
+  free(dist);
+  return n;
+}

@@ -167,6 +167,23 @@ int oracle_detect_and_compute_gpu(const uint8_t* img, int w, int h, int stride, 
 void oracle_build_level(const uint8_t* img, int w, int h, int stride, const oracle_orb_params* p, int level,
                         uint8_t* dst);
 
+/* ---- next row: descriptor matching ---------------- */
+
+/* flann->knnMatch(des1, des2, matches, 2)  [feature_matching.cpp:166-168,
+ * feature_tracking.cpp:203-204] restated as EXACT brute-force Hamming 2-NN (the
+ * reference's FLANN index -- LSH for ORB, feature_tracking.cpp:32 -- is an
+ * approximate search inside OpenCV, which is absent: PARITY UNPINNED).
+ * idx/dist: nq x 2 (best, second best); ties keep the lower train index;
+ * entries are -1 when the train set has fewer than 1 / 2 descriptors. */
+void oracle_knn2(const uint8_t* query, int nq, const uint8_t* train, int nt, int32_t* idx, int32_t* dist);
+
+/* the ratio test of feature_matching.cpp:172-181: keep query i iff it has two
+ * neighbours and (float)d1 < ratio * (float)d2 evaluated in double like the
+ * reference's `m.distance < 0.8 * n.distance`.  Returns the number of matches;
+ * query_idx/train_idx/dist1 (optional) hold them in query order. */
+int oracle_match_ratio(const uint8_t* query, int nq, const uint8_t* train, int nt, double ratio,
+                       int32_t* query_idx, int32_t* train_idx, int32_t* dist1);
+
 #ifdef __cplusplus
 }
 #endif

@@ -242,3 +242,23 @@ def detect_and_compute_gpu(img, params):
 def load_kitti(i=0):
     z = np.load(os.path.join(ROOT, "tests", "golden", "kitti_%06d.npz" % i))
     return z["image"]
+
+
+def knn2(query, train):
+    query = np.ascontiguousarray(query, np.uint8).reshape(-1, 32)
+    train = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)
+    idx = np.zeros((max(len(query), 1), 2), np.int32)
+    dist = np.zeros((max(len(query), 1), 2), np.int32)
+    lib().oracle_knn2(_p(query, u8p), len(query), _p(train, u8p), len(train), _p(idx, i32p), _p(dist, i32p))
+    return idx[:len(query)].copy(), dist[:len(query)].copy()
+
+
+def match_ratio(query, train, ratio=0.8):
+    query = np.ascontiguousarray(query, np.uint8).reshape(-1, 32)
+    train = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)
+    n = max(len(query), 1)
+    qi, ti, d1 = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    f = lib().oracle_match_ratio
+    f.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_double, i32p, i32p, i32p]
+    m = f(_p(query, u8p), len(query), _p(train, u8p), len(train), ratio, _p(qi, i32p), _p(ti, i32p), _p(d1, i32p))
+    return qi[:m].copy(), ti[:m].copy(), d1[:m].copy()

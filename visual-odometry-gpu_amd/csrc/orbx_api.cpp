@@ -94,6 +94,8 @@ struct orbx_ctx {
 
   // stage-API scratch (grown on demand; never touched by the batched path)
   DevBuf s_img_a, s_img_b, s_f32, s_u16, s_mask, s_kps, s_f32b, s_desc, s_i32, s_kern;
+  DevBuf m_q, m_t, m_idx, m_dist, m_match, m_cnt;  // matcher (stage API and batch)
+  int match_pairs = 0;
 
   int timing = 0;  // 0 off, 1 all stages, 2 blur + fast only
   int fast_early = 1;
@@ -601,8 +603,8 @@ void orbx_destroy(orbx_ctx* c) {
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_out) (void)hipHostFree(c->h_out);
-  DevBuf* sb[] = {&c->s_img_a, &c->s_img_b, &c->s_f32,  &c->s_u16, &c->s_mask,
-                  &c->s_kps,   &c->s_f32b,  &c->s_desc, &c->s_i32, &c->s_kern};
+  DevBuf* sb[] = {&c->s_img_a, &c->s_img_b, &c->s_f32,  &c->s_u16, &c->s_mask, &c->s_kps,   &c->s_f32b, &c->s_desc,
+                  &c->s_i32,   &c->s_kern,  &c->m_q,    &c->m_t,   &c->m_idx,  &c->m_dist,  &c->m_match, &c->m_cnt};
   for (DevBuf* b : sb)
     if (b->p) (void)hipFree(b->p);
   for (auto& e : c->ev)
@@ -1164,6 +1166,120 @@ int orbx_select_top(orbx_ctx* c, const float* responses, int n, int keep, int32_
   HIPCHK(c, hipMemcpyAsync(indices, c->s_i32.p, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return ORBX_OK;
+}
+
+// ---- descriptor matching (next row) -----------------------------------------
+
+static int knn_host(orbx_ctx* c, const orbx_descriptor* query, int nq, const orbx_descriptor* train, int nt,
+                    double ratio, std::vector<int32_t>* idx, std::vector<int32_t>* dist,
+                    std::vector<int32_t>* match) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  if (nq < 0 || nt < 0 || (nq > 0 && !query) || (nt > 0 && !train))
+    return fail(c, ORBX_ERR_INVALID_ARG, "bad matcher arguments");
+  idx->assign((size_t)2 * nq, -1);
+  dist->assign((size_t)2 * nq, -1);
+  match->assign((size_t)nq, -1);
+  if (nq == 0) return ORBX_OK;
+  int st;
+  if ((st = ensure(c, c->m_q, sizeof(orbx_descriptor) * (size_t)nq)) != ORBX_OK) return st;
+  if ((st = ensure(c, c->m_t, sizeof(orbx_descriptor) * (size_t)std::max(nt, 1))) != ORBX_OK) return st;
+  if ((st = ensure(c, c->m_idx, sizeof(int32_t) * 2 * (size_t)nq)) != ORBX_OK) return st;
+  if ((st = ensure(c, c->m_dist, sizeof(int32_t) * 2 * (size_t)nq)) != ORBX_OK) return st;
+  if ((st = ensure(c, c->m_match, sizeof(int32_t) * (size_t)nq)) != ORBX_OK) return st;
+  if ((st = ensure(c, c->m_cnt, 64)) != ORBX_OK) return st;
+  const int32_t cnt[2] = {nq, nt};
+  hipStream_t s = c->stream;
+  HIPCHK(c, hipMemcpyAsync(c->m_cnt.p, cnt, sizeof(cnt), hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->m_q.p, query, sizeof(orbx_descriptor) * (size_t)nq, hipMemcpyHostToDevice, s));
+  if (nt > 0) HIPCHK(c, hipMemcpyAsync(c->m_t.p, train, sizeof(orbx_descriptor) * (size_t)nt, hipMemcpyHostToDevice, s));
+  HIPCHK(c, orbx_launch_knn2(s, 1, nq, (const orbx_descriptor*)c->m_q.p, (const int32_t*)c->m_cnt.p, 0,
+                             (const orbx_descriptor*)c->m_t.p, (const int32_t*)c->m_cnt.p + 1, 0, ratio,
+                             (int32_t*)c->m_idx.p, (int32_t*)c->m_dist.p, (int32_t*)c->m_match.p, 0));
+  HIPCHK(c, hipMemcpyAsync(idx->data(), c->m_idx.p, sizeof(int32_t) * 2 * (size_t)nq, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(dist->data(), c->m_dist.p, sizeof(int32_t) * 2 * (size_t)nq, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(match->data(), c->m_match.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  c->match_pairs = 0;  // the scratch no longer holds a batch's matches
+  return ORBX_OK;
+}
+
+static int compact_matches(orbx_ctx* c, const int32_t* match, const int32_t* dist2, int nq, int32_t* query_idx,
+                           int32_t* train_idx, int32_t* dist1, int capacity, int* count) {
+  int n = 0;
+  for (int i = 0; i < nq; i++)
+    if (match[i] >= 0) {
+      if (n < capacity) {
+        query_idx[n] = i;
+        train_idx[n] = match[i];
+        if (dist1) dist1[n] = dist2[2 * i];
+      }
+      n++;
+    }
+  *count = n;
+  return n > capacity ? fail(c, ORBX_ERR_CAPACITY, "capacity smaller than match count") : (int)ORBX_OK;
+}
+
+int orbx_knn2(orbx_ctx* c, const orbx_descriptor* query, int nq, const orbx_descriptor* train, int nt,
+              int32_t* idx, int32_t* dist) {
+  if (c && nq > 0 && (!idx || !dist)) return fail(c, ORBX_ERR_INVALID_ARG, "idx/dist is NULL");
+  std::vector<int32_t> vi, vd, vm;
+  int st = knn_host(c, query, nq, train, nt, 0.8, &vi, &vd, &vm);
+  if (st != ORBX_OK) return st;
+  if (nq > 0) {
+    std::memcpy(idx, vi.data(), sizeof(int32_t) * 2 * (size_t)nq);
+    std::memcpy(dist, vd.data(), sizeof(int32_t) * 2 * (size_t)nq);
+  }
+  return ORBX_OK;
+}
+
+int orbx_match_ratio(orbx_ctx* c, const orbx_descriptor* query, int nq, const orbx_descriptor* train, int nt,
+                     double ratio, int32_t* query_idx, int32_t* train_idx, int32_t* dist1, int capacity, int* count) {
+  if (c && (!count || capacity < 0 || (capacity > 0 && (!query_idx || !train_idx))))
+    return fail(c, ORBX_ERR_INVALID_ARG, "bad match output arguments");
+  std::vector<int32_t> vi, vd, vm;
+  int st = knn_host(c, query, nq, train, nt, ratio, &vi, &vd, &vm);
+  if (st != ORBX_OK) return st;
+  return compact_matches(c, vm.data(), vd.data(), nq, query_idx, train_idx, dist1, capacity, count);
+}
+
+int orbx_batch_match_consecutive(orbx_ctx* c, double ratio) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  if (c->last_n < 2) return fail(c, ORBX_ERR_INVALID_ARG, "needs a batch of at least two frames");
+  const int n = c->last_n, cap = c->plan.out_cap > 0 ? c->plan.out_cap : 1;
+  const size_t e = (size_t)(n - 1) * cap;
+  int st;
+  if ((st = ensure(c, c->m_idx, sizeof(int32_t) * 2 * e)) != ORBX_OK) return st;
+  if ((st = ensure(c, c->m_dist, sizeof(int32_t) * 2 * e)) != ORBX_OK) return st;
+  if ((st = ensure(c, c->m_match, sizeof(int32_t) * e)) != ORBX_OK) return st;
+  const OutLayout& o = c->out_layout;
+  const int32_t* counts = (const int32_t*)(c->d_out + o.counts);
+  const orbx_descriptor* desc = (const orbx_descriptor*)(c->d_out + o.desc);
+  hipStream_t s = c->last_stream ? c->last_stream : c->stream;
+  // pair p: query = frame p, train = frame p+1 (same arrays, shifted by one slot block)
+  HIPCHK(c, orbx_launch_knn2(s, n - 1, cap, desc, counts, (size_t)cap, desc + cap, counts + 1, (size_t)cap, ratio,
+                             (int32_t*)c->m_idx.p, (int32_t*)c->m_dist.p, (int32_t*)c->m_match.p, (size_t)cap));
+  c->match_pairs = n - 1;
+  return ORBX_OK;
+}
+
+int orbx_batch_match_fetch(orbx_ctx* c, int pair, int32_t* query_idx, int32_t* train_idx, int32_t* dist1,
+                           int capacity, int* count) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  if (!count || capacity < 0 || (capacity > 0 && (!query_idx || !train_idx)))
+    return fail(c, ORBX_ERR_INVALID_ARG, "bad match output arguments");
+  if (pair < 0 || pair >= c->match_pairs) return fail(c, ORBX_ERR_INVALID_ARG, "pair outside the last matched batch");
+  const int cap = c->plan.out_cap > 0 ? c->plan.out_cap : 1;
+  hipStream_t s = c->last_stream ? c->last_stream : c->stream;
+  int32_t nq = 0;
+  std::vector<int32_t> vm((size_t)cap), vd((size_t)2 * cap);
+  HIPCHK(c, hipMemcpyAsync(&nq, (const int32_t*)(c->d_out + c->out_layout.counts) + pair, sizeof(int32_t),
+                           hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(vm.data(), (const int32_t*)c->m_match.p + (size_t)pair * cap, sizeof(int32_t) * cap,
+                           hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(vd.data(), (const int32_t*)c->m_dist.p + (size_t)2 * pair * cap, sizeof(int32_t) * 2 * cap,
+                           hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  return compact_matches(c, vm.data(), vd.data(), nq, query_idx, train_idx, dist1, capacity, count);
 }
 
 }  // extern "C"

@@ -127,3 +127,8 @@ hipError_t orbx_launch_nms_f32(hipStream_t s, const float* d_scores, int w, int 
 hipError_t orbx_launch_conv2d(hipStream_t s, const uint8_t* d_img, int w, int h, int pitch, const float* d_kernel,
                               int K, int reflect_pad, uint8_t* d_dst, int dst_pitch);
 hipError_t orbx_launch_select_flat(hipStream_t s, const float* d_resp, int n, int keep, int32_t* d_idx);
+
+// 256-bit Hamming 2-NN + ratio test over `npairs` (query set, train set) pairs
+hipError_t orbx_launch_knn2(hipStream_t s, int npairs, int max_nq, const orbx_descriptor* d_q, const int32_t* d_qcount,
+                            size_t qstride, const orbx_descriptor* d_t, const int32_t* d_tcount, size_t tstride,
+                            double ratio, int32_t* d_idx, int32_t* d_dist, int32_t* d_match, size_t ostride);

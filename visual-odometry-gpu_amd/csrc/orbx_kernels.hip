@@ -1740,6 +1740,72 @@ __global__ __launch_bounds__(256) void k_describe_flat(const uint8_t* __restrict
 }
 
 // ---------------------------------------------------------------------------
+// 8. Hamming 2-nearest-neighbour search over 256-bit descriptors + ratio test
+//    (next row, SURVEY.md §8f rank 1: flann->knnMatch(des1, des2, matches, 2) and
+//    the `m.distance < 0.8 * n.distance` filter, src/feature_matching.cpp:166-181,
+//    src/feature_tracking.cpp:203-219 -- exact brute force instead of FLANN's
+//    approximate LSH index).
+//    One thread owns one query descriptor (4 x u64 in registers); the train set
+//    streams through LDS in tiles of 256 descriptors (every lane reads the same
+//    16-byte words: broadcast, conflict-free); distance = 4 x popcount(xor).
+//    Ties keep the lower train index.  blockIdx.y = pair p: query set p is
+//    qbase + p*qstride with qcount[p] entries, train set likewise.
+__global__ __launch_bounds__(256) void k_knn2(const orbx_descriptor* __restrict__ qbase,
+                                              const int32_t* __restrict__ qcount, size_t qstride,
+                                              const orbx_descriptor* __restrict__ tbase,
+                                              const int32_t* __restrict__ tcount, size_t tstride, double ratio,
+                                              int32_t* __restrict__ knn_idx, int32_t* __restrict__ knn_dist,
+                                              int32_t* __restrict__ match, size_t ostride) {
+  __shared__ __attribute__((aligned(16))) uint4 s_t[256 * 2];
+  const int p = blockIdx.y, tid = threadIdx.x;
+  const int nq = qcount[p], nt = tcount[p];
+  if ((int)(blockIdx.x * 256) >= nq) return;  // whole workgroup
+  const int q = blockIdx.x * 256 + tid;
+  const bool valid = q < nq;
+  const uint4* qp = reinterpret_cast<const uint4*>(qbase + p * qstride + (valid ? q : 0));
+  const uint4 qa = qp[0], qb = qp[1];
+  const u64 q0 = ((u64)qa.y << 32) | qa.x, q1 = ((u64)qa.w << 32) | qa.z;
+  const u64 q2 = ((u64)qb.y << 32) | qb.x, q3 = ((u64)qb.w << 32) | qb.z;
+  int d1 = 1 << 30, d2 = 1 << 30, j1 = -1, j2 = -1;
+  const orbx_descriptor* tp = tbase + p * tstride;
+  for (int t0 = 0; t0 < nt; t0 += 256) {
+    const int m = min(256, nt - t0);
+    if (tid < m) {
+      const uint4* src = reinterpret_cast<const uint4*>(tp + t0 + tid);
+      s_t[2 * tid] = src[0];
+      s_t[2 * tid + 1] = src[1];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < m; j++) {
+      const uint4 a = s_t[2 * j], b = s_t[2 * j + 1];
+      const int d = __popcll(q0 ^ (((u64)a.y << 32) | a.x)) + __popcll(q1 ^ (((u64)a.w << 32) | a.z)) +
+                    __popcll(q2 ^ (((u64)b.y << 32) | b.x)) + __popcll(q3 ^ (((u64)b.w << 32) | b.z));
+      if (d < d1) {
+        d2 = d1;
+        j2 = j1;
+        d1 = d;
+        j1 = t0 + j;
+      } else if (d < d2) {
+        d2 = d;
+        j2 = t0 + j;
+      }
+    }
+    __syncthreads();
+  }
+  if (valid) {
+    const size_t o = p * ostride + q;
+    knn_idx[2 * o] = j1;
+    knn_idx[2 * o + 1] = j2;
+    knn_dist[2 * o] = j1 >= 0 ? d1 : -1;
+    knn_dist[2 * o + 1] = j2 >= 0 ? d2 : -1;
+    // DMatch::distance is a float; the reference compares in double (0.8 is a double literal)
+    const bool pass = j2 >= 0 && (double)(float)d1 < ratio * (double)(float)d2;
+    match[o] = pass ? j1 : -1;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // stage-level helpers (not on the batched hot path)
 
 // thresholded NMS of an arbitrary float score map (src/cuda/NMS.cu:21-128):
@@ -1981,5 +2047,15 @@ hipError_t orbx_launch_select_flat(hipStream_t s, const float* d_resp, int n, in
   int blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(k_select_flat, dim3(blocks), dim3(256), 0, s, d_resp, n, keep, d_idx);
+  return ORBX_LAUNCH_CHECK();
+}
+
+hipError_t orbx_launch_knn2(hipStream_t s, int npairs, int max_nq, const orbx_descriptor* d_q, const int32_t* d_qcount,
+                            size_t qstride, const orbx_descriptor* d_t, const int32_t* d_tcount, size_t tstride,
+                            double ratio, int32_t* d_idx, int32_t* d_dist, int32_t* d_match, size_t ostride) {
+  if (npairs <= 0 || max_nq <= 0) return hipSuccess;
+  dim3 grid((max_nq + 255) / 256, npairs);
+  hipLaunchKernelGGL(k_knn2, grid, dim3(256), 0, s, d_q, d_qcount, qstride, d_t, d_tcount, tstride, ratio, d_idx,
+                     d_dist, d_match, ostride);
   return ORBX_LAUNCH_CHECK();
 }

@@ -31,7 +31,7 @@ EXPORTS = [
     "orbx_last_stage_times", "orbx_stage_times_history", "orbx_bench_stage", "orbx_set_fast_early_exit", "orbx_fast_score", "orbx_nms", "orbx_fast",
     "orbx_orientations", "orbx_brief", "orbx_harris", "orbx_blur5_sep", "orbx_blur5_273", "orbx_conv2d",
     "orbx_gaussian_blur_conv", "orbx_gaussian_kernel", "orbx_sobel", "orbx_build_pyramid_level",
-    "orbx_select_top",
+    "orbx_select_top", "orbx_knn2", "orbx_match_ratio", "orbx_batch_match_consecutive", "orbx_batch_match_fetch",
 ]
 
 
@@ -377,6 +377,49 @@ class Context:
         kept = C.c_int(0)
         self._chk(self._lib.orbx_select_top(self._h, _ptr(responses), len(responses), keep, _ptr(idx), C.byref(kept)))
         return idx[:kept.value].copy()
+
+
+def _desc(d):
+    d = np.ascontiguousarray(d, dtype=np.uint8).reshape(-1, 32)
+    return d
+
+
+def _matcher_methods():
+    def knn2(self, query, train):
+        """flann->knnMatch(des1, des2, matches, 2) as exact Hamming 2-NN: (idx[nq,2], dist[nq,2])."""
+        q, t = _desc(query), _desc(train)
+        idx = np.full((max(len(q), 1), 2), -1, np.int32)
+        dist = np.full((max(len(q), 1), 2), -1, np.int32)
+        self._chk(self._lib.orbx_knn2(self._h, _ptr(q), len(q), _ptr(t), len(t), _ptr(idx), _ptr(dist)))
+        return idx[:len(q)].copy(), dist[:len(q)].copy()
+
+    def match_ratio(self, query, train, ratio=0.8):
+        """knnMatch + `m.distance < ratio * n.distance` (feature_matching.cpp:166-181)."""
+        q, t = _desc(query), _desc(train)
+        n = max(len(q), 1)
+        qi, ti, d1 = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        cnt = C.c_int(0)
+        self._chk(self._lib.orbx_match_ratio(self._h, _ptr(q), len(q), _ptr(t), len(t), C.c_double(ratio), _ptr(qi),
+                                             _ptr(ti), _ptr(d1), n, C.byref(cnt)))
+        m = cnt.value
+        return qi[:m].copy(), ti[:m].copy(), d1[:m].copy()
+
+    def batch_match_consecutive(self, ratio=0.8):
+        self._chk(self._lib.orbx_batch_match_consecutive(self._h, C.c_double(ratio)))
+
+    def batch_match_fetch(self, pair, capacity):
+        qi, ti, d1 = np.zeros(capacity, np.int32), np.zeros(capacity, np.int32), np.zeros(capacity, np.int32)
+        cnt = C.c_int(0)
+        self._chk(self._lib.orbx_batch_match_fetch(self._h, pair, _ptr(qi), _ptr(ti), _ptr(d1), capacity,
+                                                   C.byref(cnt)))
+        m = cnt.value
+        return qi[:m].copy(), ti[:m].copy(), d1[:m].copy()
+
+    for f in (knn2, match_ratio, batch_match_consecutive, batch_match_fetch):
+        setattr(Context, f.__name__, f)
+
+
+_matcher_methods()
 
 
 def gaussian_kernel(K, sigma=-1.0):
