@@ -205,6 +205,17 @@ def main():
         res = ctx.batch_fetch(0, B, cap)
     dt_d2h = (time.perf_counter() - t1) / max(1, min(args.steps, 5))
 
+    # next row, informational: Hamming 2-NN + ratio test of every consecutive
+    # frame pair of the batch, on the device-resident descriptors (not part of `value`)
+    ctx.batch_device(d_frames.data_ptr(), B, W, H)
+    ctx.wait()
+    t3 = time.perf_counter()
+    for _ in range(5):
+        ctx.batch_match_consecutive(0.8)
+    ctx.wait()
+    match_ms = (time.perf_counter() - t3) / 5 * 1e3
+    n_matches = len(ctx.batch_match_fetch(0, cap)[0]) if B > 1 else 0
+
     # per-frame host-in / host-out call (orbx_detect_and_compute, the reference's own call shape:
     # H2D of the frame + the whole path + one D2H of the results + sync), BASELINE.json configs[1]
     single = None
@@ -270,6 +281,8 @@ def main():
             "stage_ms_per_step": stage_ms,
             "fps_with_d2h": world * B / dt_d2h,
             "single_frame_host_to_host": single,
+            "match_consecutive": {"ms_per_batch": match_ms, "pairs": B - 1, "matches_pair0": n_matches,
+                                  "what": "Hamming 2-NN + 0.8 ratio test, frame i -> i+1, device-resident"},
             "keypoints_per_step": n_kp, "desc_checksum": csum,
         }
         if not args.no_cpu_baseline:

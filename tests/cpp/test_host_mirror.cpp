@@ -144,6 +144,35 @@ int main(int argc, char** argv) {
     }
     EXPECT(threw, "size mismatch must throw");
   }
+  // ---- get_matches() shape (feature_matching.cpp:155-183): detect on two frames, knnMatch, ratio test
+  {
+    std::vector<uint8_t> px2(px);  // second frame: the first one shifted by (3, 2)
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) px2[(size_t)y * w + x] = px[(size_t)((y + 2) % h) * w + (x + 3) % w];
+    ORB orb(1000);
+    std::vector<Keypoint> k1, k2;
+    std::vector<float> a1, a2;
+    std::vector<ORBDescriptor> d1, d2;
+    orb.detectAndCompute(image, k1, a1, d1);
+    orb.detectAndCompute(orbx::Image(px2.data(), w, h), k2, a2, d2);
+    HammingMatcher matcher;
+    std::vector<std::vector<DMatch>> matches;
+    matcher.knnMatch(d1, d2, matches, 2);
+    std::vector<int32_t> oi(2 * d1.size()), od(2 * d1.size());
+    oracle_knn2(d1[0].data, (int)d1.size(), d2[0].data, (int)d2.size(), oi.data(), od.data());
+    int bad = 0, good = 0;
+    for (size_t i = 0; i < matches.size(); i++) {
+      if (matches[i].size() < 2) continue;  // :174
+      const DMatch& m = matches[i][0];
+      const DMatch& n = matches[i][1];
+      if (m.trainIdx != oi[2 * i] || n.trainIdx != oi[2 * i + 1] || (int)m.distance != od[2 * i]) bad++;
+      if (m.distance < 0.8 * n.distance) good++;  // :177
+    }
+    std::vector<DMatch> rm = matcher.ratioMatch(d1, d2, 0.8);
+    EXPECT(bad == 0, "%d knnMatch mismatches", bad);
+    EXPECT((int)rm.size() == good && good > 100, "ratio matches %zu vs %d", rm.size(), good);
+    std::printf("HammingMatcher: %zu x %zu descriptors, %d ratio matches\n", d1.size(), d2.size(), good);
+  }
   std::printf(fails ? "FAILED (%d)\n" : "OK\n", fails);
   return fails ? 1 : 0;
 }

@@ -375,3 +375,51 @@ class ORBCPU {
  private:
   ORB orb_;
 };
+
+// ---- descriptor matching (next row: src/feature_matching.cpp:166-181) ---------
+// Call shape of cv::DescriptorMatcher::knnMatch(des1, des2, matches, 2) as used by
+// VisualOdom::get_matches; exact brute-force Hamming instead of FLANN's LSH.
+
+struct DMatch {  // cv::DMatch
+  int queryIdx = -1, trainIdx = -1;
+  float distance = 0.f;
+};
+
+class HammingMatcher {
+ public:
+  HammingMatcher() : ctx_(orbx::detail::stage_ctx()) {}
+  // matches[i] holds up to k (= 2) neighbours of des1[i], best first
+  void knnMatch(const std::vector<ORBDescriptor>& des1, const std::vector<ORBDescriptor>& des2,
+                std::vector<std::vector<DMatch>>& matches, int k = 2) {
+    if (k != 2) throw std::runtime_error("HammingMatcher::knnMatch: only k = 2 (the reference's call) exists");
+    orbx_ctx* c = ctx_->get(8, 8);
+    std::vector<int32_t> idx(2 * des1.size()), dist(2 * des1.size());
+    orbx::detail::check(c,
+                        orbx_knn2(c, reinterpret_cast<const orbx_descriptor*>(des1.data()), (int)des1.size(),
+                                  reinterpret_cast<const orbx_descriptor*>(des2.data()), (int)des2.size(), idx.data(),
+                                  dist.data()),
+                        "knnMatch");
+    matches.assign(des1.size(), {});
+    for (size_t i = 0; i < des1.size(); i++)
+      for (int j = 0; j < 2; j++)
+        if (idx[2 * i + j] >= 0) matches[i].push_back(DMatch{(int)i, idx[2 * i + j], (float)dist[2 * i + j]});
+  }
+  // knnMatch + `m.distance < ratio * n.distance` (feature_matching.cpp:172-181), in one device pass
+  std::vector<DMatch> ratioMatch(const std::vector<ORBDescriptor>& des1, const std::vector<ORBDescriptor>& des2,
+                                 double ratio = 0.8) {
+    orbx_ctx* c = ctx_->get(8, 8);
+    std::vector<int32_t> qi(des1.size()), ti(des1.size()), d1(des1.size());
+    int n = 0;
+    orbx::detail::check(c,
+                        orbx_match_ratio(c, reinterpret_cast<const orbx_descriptor*>(des1.data()), (int)des1.size(),
+                                         reinterpret_cast<const orbx_descriptor*>(des2.data()), (int)des2.size(), ratio,
+                                         qi.data(), ti.data(), d1.data(), (int)des1.size(), &n),
+                        "ratioMatch");
+    std::vector<DMatch> out(n);
+    for (int i = 0; i < n; i++) out[i] = DMatch{qi[i], ti[i], (float)d1[i]};
+    return out;
+  }
+
+ private:
+  std::shared_ptr<orbx::detail::Ctx> ctx_;
+};
