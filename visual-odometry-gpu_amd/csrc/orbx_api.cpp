@@ -70,6 +70,15 @@ struct orbx_ctx {
   OrbxTileMap tm_pyr{}, tm_pyr2{}, tm_blur{}, tm_blur2{};
   OrbxBandMap bm_fast{};
   unsigned long long* d_row_stat = nullptr;
+  // per-workgroup tile descriptor tables (see OrbxTileDesc)
+  OrbxTileDesc* d_tiles_fast = nullptr;  // band-major, built for fast_tiles_n frames
+  size_t tiles_fast_capacity = 0;
+  int fast_tiles_n = 0, fast_tiles_count = 0;
+  OrbxTileDesc* d_tiles_blur2 = nullptr;
+  OrbxTileDesc* d_tiles_pyr2 = nullptr;
+  size_t tiles_frame_capacity = 0;
+  int blur2_tiles_count = 0, pyr2_tiles_count = 0;
+  DevBuf s_tiles;  // stage-API tables
   std::vector<OrbxResizeTap> h_taps;
   int plan_w = 0, plan_h = 0;
 
@@ -201,6 +210,62 @@ int make_bandmap(const OrbxPlan& plan, OrbxBandMap* bm, std::string* why) {
   }
   for (int b = nb; b <= ORBX_MAX_BANDS; b++) bm->band_begin[b] = acc;
   return ORBX_OK;
+}
+
+// FAST tiles of n frames in band-major order (levels shrink with the level index,
+// so the levels that have a tile row b are always a prefix of the level list)
+void build_fast_tiles(const OrbxPlan& plan, const OrbxBandMap& bm, int n, std::vector<OrbxTileDesc>* out) {
+  out->clear();
+  out->reserve((size_t)bm.band_begin[bm.nbands] * n);
+  for (int b = 0; b < bm.nbands; b++)
+    for (int f = 0; f < n; f++)
+      for (int l = 0; l < plan.nlevels; l++) {
+        if (bm.tiles_y[l] <= b) continue;
+        const OrbxLevel& L = plan.L[l];
+        for (int tx = 0; tx < bm.tiles_x[l]; tx++) {
+          OrbxTileDesc d{};
+          d.l = l;
+          d.tx = tx;
+          d.ty = b;
+          d.f = f;
+          d.w = L.w;
+          d.h = L.h;
+          d.pitch = L.pitch;
+          d.u0 = L.cap;
+          d.u1 = L.mask_wpr;
+          d.u2 = bm.tiles_x[l];
+          d.stat_index = (uint32_t)(((size_t)f * ORBX_MAX_LEVELS + l) * ORBX_MAX_BANDS);
+          d.img_off = (uint64_t)f * plan.frame_bytes + L.img_off;
+          d.mask_off = (uint64_t)f * plan.mask_words + L.mask_off;
+          out->push_back(d);
+        }
+      }
+}
+
+// tiles of ONE frame, level-major, for the blur / pyramid kernels (blockIdx.y = frame)
+void build_frame_tiles(const OrbxPlan& plan, int tw, int th, bool pyramid_fields, std::vector<OrbxTileDesc>* out) {
+  out->clear();
+  for (int l = 0; l < plan.nlevels; l++) {
+    const OrbxLevel& L = plan.L[l];
+    const int ntx = (L.pitch + tw - 1) / tw, nty = (L.h + th - 1) / th;
+    for (int ty = 0; ty < nty; ty++)
+      for (int tx = 0; tx < ntx; tx++) {
+        OrbxTileDesc d{};
+        d.l = l;
+        d.tx = tx;
+        d.ty = ty;
+        d.w = L.w;
+        d.h = L.h;
+        d.pitch = L.pitch;
+        if (pyramid_fields) {
+          d.u0 = L.xtab_off;
+          d.u1 = L.ytab_off;
+          d.u2 = L.win8;
+        }
+        d.img_off = (uint64_t)L.img_off;
+        out->push_back(d);
+      }
+  }
 }
 
 int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string* why) {
@@ -373,8 +438,34 @@ int set_plan(orbx_ctx* c, int w, int h) {
   make_tilemap(plan, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &c->tm_blur);
   make_tilemap(plan, ORBX_BLUR2_TW, 4 * orbx_blur2_rows_per_wave(), true, &c->tm_blur2);
   if ((st = make_bandmap(plan, &c->bm_fast, &why)) != ORBX_OK) return fail(c, st, why);
+  {
+    std::vector<OrbxTileDesc> t;
+    build_frame_tiles(plan, ORBX_BLUR2_TW, 4 * orbx_blur2_rows_per_wave(), false, &t);
+    if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "blur tile table exceeds pool");
+    HIPCHK(c, hipMemcpy(c->d_tiles_blur2, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
+    c->blur2_tiles_count = (int)t.size();
+    build_frame_tiles(plan, ORBX_PYR2_TW, ORBX_PYR2_TH, true, &t);
+    if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "pyramid tile table exceeds pool");
+    HIPCHK(c, hipMemcpy(c->d_tiles_pyr2, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
+    c->pyr2_tiles_count = (int)t.size();
+  }
+  c->fast_tiles_n = 0;  // the FAST table depends on the plan and on the batch size
   c->plan_w = w;
   c->plan_h = h;
+  return ORBX_OK;
+}
+
+// FAST tile table for n frames of the current plan (rebuilt only when n or the plan changes)
+int ensure_fast_tiles(orbx_ctx* c, int n) {
+  if (c->fast_tiles_n == n) return ORBX_OK;
+  std::vector<OrbxTileDesc> t;
+  build_fast_tiles(c->plan, c->bm_fast, n, &t);
+  if (t.size() > c->tiles_fast_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "FAST tile table exceeds pool");
+  // an in-flight batch may still be reading the previous table
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->d_tiles_fast, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
+  c->fast_tiles_n = n;
+  c->fast_tiles_count = (int)t.size();
   return ORBX_OK;
 }
 
@@ -387,7 +478,8 @@ hipError_t launch_pyramid_auto(orbx_ctx* c, hipStream_t s, int n, const uint8_t*
   }();
   if (impl == 1)
     return orbx_launch_pyramid(s, c->plan, c->tm_pyr, n, d_in, in_stride, in_frame_stride, c->d_taps, c->d_pyr);
-  return orbx_launch_pyramid2(s, c->plan, c->tm_pyr2, n, d_in, in_stride, in_frame_stride, c->d_taps, c->d_pyr);
+  return orbx_launch_pyramid2(s, c->d_tiles_pyr2, c->pyr2_tiles_count, c->plan.frame_bytes, c->plan.w0, c->plan.h0, n,
+                              d_in, in_stride, in_frame_stride, c->d_taps, c->d_pyr);
 }
 
 int fast_ablate() {  // timing diagnostics only: results are wrong when non-zero
@@ -405,6 +497,7 @@ const uint8_t* final_pyr(const orbx_ctx* c);
 // first `cap` row-major survivors exit early (see decode_band in the kernels);
 // ORBX_FAST_EARLY=0 disables that (every tile does the full work).
 hipError_t launch_fast_whole(orbx_ctx* c, hipStream_t s, int n, OrbxFastParams fp) {
+  if (c->fast_tiles_n != n) return hipErrorInvalidValue;  // ensure_fast_tiles() must have run
   static const int early_env = [] {
     const char* e = getenv("ORBX_FAST_EARLY");
     return e ? atoi(e) : 1;
@@ -415,13 +508,13 @@ hipError_t launch_fast_whole(orbx_ctx* c, hipStream_t s, int n, OrbxFastParams f
     hipError_t e = hipMemsetAsync(stat, 0, (size_t)n * ORBX_MAX_LEVELS * ORBX_MAX_BANDS * 8, s);
     if (e != hipSuccess) return e;
   }
-  return orbx_launch_fast_nms(s, c->plan, c->bm_fast, n, final_pyr(c), fp, c->d_mask, nullptr, stat);
+  return orbx_launch_fast_nms(s, c->d_tiles_fast, c->fast_tiles_count, final_pyr(c), fp, c->d_mask, nullptr, stat);
 }
 
 // separable kind -> register-streaming kernel; /273 kind -> LDS tile kernel.
 // ORBX_BLUR_IMPL=1 forces the first-generation kernel (A/B timing).
-hipError_t launch_blur_auto(hipStream_t s, const OrbxPlan& P, const OrbxTileMap& tm1, const OrbxTileMap& tm2,
-                            int n, const uint8_t* src, uint8_t* dst, int first_level, int kind) {
+hipError_t launch_blur_auto(hipStream_t s, const OrbxPlan& P, const OrbxTileMap& tm1, const OrbxTileDesc* tiles2,
+                            int ntiles2, int n, const uint8_t* src, uint8_t* dst, int first_level, int kind) {
   static const int impl = [] {
     const char* e = getenv("ORBX_BLUR_IMPL");
     return e ? atoi(e) : 2;
@@ -434,7 +527,8 @@ hipError_t launch_blur_auto(hipStream_t s, const OrbxPlan& P, const OrbxTileMap&
     return e ? atoi(e) : 0;
   }();
   if (copy_all) first_level = ORBX_MAX_LEVELS;
-  if (kind == ORBX_BLUR_SEP16 && impl != 1) return orbx_launch_blur2(s, P, tm2, n, src, dst, first_level);
+  if (kind == ORBX_BLUR_SEP16 && impl != 1)
+    return orbx_launch_blur2(s, tiles2, ntiles2, P.frame_bytes, n, src, dst, first_level);
   return orbx_launch_blur(s, P, tm1, n, src, dst, first_level, kind);
 }
 const uint8_t* final_pyr(const orbx_ctx* c) { return blur_enabled(c) ? c->d_pyr_blur : c->d_pyr; }
@@ -456,10 +550,11 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   HIPCHK(c, launch_pyramid_auto(c, s, n, d_frames, row_stride, frame_stride));
   HIPCHK(c, mark(1, true));
   if (blur_enabled(c))
-    HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->tm_blur2, n, c->d_pyr, c->d_pyr_blur,
+    HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->d_tiles_blur2, c->blur2_tiles_count, n, c->d_pyr, c->d_pyr_blur,
                                c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
   HIPCHK(c, mark(2, true));
   OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2, fast_ablate()};
+  if ((st = ensure_fast_tiles(c, n)) != ORBX_OK) return st;
   HIPCHK(c, launch_fast_whole(c, s, n, fp));
   HIPCHK(c, mark(3, true));
   HIPCHK(c, orbx_launch_compact(s, P, n, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total, 0));
@@ -599,12 +694,12 @@ void orbx_destroy(orbx_ctx* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* bufs[] = {c->d_in,   c->d_pyr,  c->d_pyr_blur, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total,
-                  c->d_resp, c->d_taps, c->d_gauss,    c->d_out, c->d_row_stat};
+                  c->d_resp, c->d_taps, c->d_gauss,    c->d_out, c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur2, c->d_tiles_pyr2};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_out) (void)hipHostFree(c->h_out);
   DevBuf* sb[] = {&c->s_img_a, &c->s_img_b, &c->s_f32,  &c->s_u16, &c->s_mask, &c->s_kps,   &c->s_f32b, &c->s_desc,
-                  &c->s_i32,   &c->s_kern,  &c->m_q,    &c->m_t,   &c->m_idx,  &c->m_dist,  &c->m_match, &c->m_cnt};
+                  &c->s_i32,   &c->s_kern,  &c->s_tiles, &c->m_q,    &c->m_t,   &c->m_idx,  &c->m_dist,  &c->m_match, &c->m_cnt};
   for (DevBuf* b : sb)
     if (b->p) (void)hipFree(b->p);
   for (auto& e : c->ev)
@@ -672,6 +767,21 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_pyr_blur, B * (size_t)M.frame_bytes + 256));
   CREATE_CHK(hipMalloc((void**)&c->d_mask, B * (size_t)M.mask_words * 8 + 256));
   CREATE_CHK(hipMalloc((void**)&c->d_row_stat, B * ORBX_MAX_LEVELS * ORBX_MAX_BANDS * 8));
+  {
+    OrbxBandMap bmm;
+    if ((st = make_bandmap(M, &bmm, &why)) != ORBX_OK) {
+      orbx_destroy(c);
+      return fail(nullptr, st, why);
+    }
+    c->tiles_fast_capacity = (size_t)bmm.band_begin[bmm.nbands] * B;
+    CREATE_CHK(hipMalloc((void**)&c->d_tiles_fast, std::max<size_t>(c->tiles_fast_capacity, 1) * sizeof(OrbxTileDesc)));
+    std::vector<OrbxTileDesc> t1, t2;
+    build_frame_tiles(M, ORBX_BLUR2_TW, 4 * 16, false, &t1);  // the smaller strip height gives the larger table
+    build_frame_tiles(M, ORBX_PYR2_TW, ORBX_PYR2_TH, true, &t2);
+    c->tiles_frame_capacity = std::max(t1.size(), t2.size()) + 64;
+    CREATE_CHK(hipMalloc((void**)&c->d_tiles_blur2, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
+    CREATE_CHK(hipMalloc((void**)&c->d_tiles_pyr2, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
+  }
   CREATE_CHK(hipMalloc((void**)&c->d_cand, B * (size_t)std::max(M.cand_total, 1) * sizeof(orbx_keypoint)));
   CREATE_CHK(hipMalloc((void**)&c->d_cand_count, B * ORBX_MAX_LEVELS * sizeof(int32_t)));
   CREATE_CHK(hipMalloc((void**)&c->d_cand_total, B * ORBX_MAX_LEVELS * sizeof(int32_t)));
@@ -867,10 +977,15 @@ int orbx_bench_stage(orbx_ctx* c, int n_frames, int stage, int reps, float* avg_
     switch (stage) {
       case ORBX_STAGE_BLUR:
         if (!blur_enabled(c)) return fail(c, ORBX_ERR_INVALID_ARG, "blur is disabled in this context");
-        HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->tm_blur2, n_frames, c->d_pyr, c->d_pyr_blur,
+        HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->d_tiles_blur2, c->blur2_tiles_count, n_frames, c->d_pyr,
+                                   c->d_pyr_blur,
                                    c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
         break;
       case ORBX_STAGE_FAST:
+        {
+          int st2 = ensure_fast_tiles(c, n_frames);
+          if (st2 != ORBX_OK) return st2;
+        }
         HIPCHK(c, launch_fast_whole(c, s, n_frames, fp));
         break;
       case ORBX_STAGE_COMPACT:
@@ -903,12 +1018,18 @@ int orbx_fast_score(orbx_ctx* c, const uint8_t* image, int width, int height, in
   OrbxBandMap bm;
   std::string why;
   if ((st = make_bandmap(P, &bm, &why)) != ORBX_OK) return fail(c, st, why);
+  std::vector<OrbxTileDesc> t;
+  build_fast_tiles(P, bm, 1, &t);
+  if ((st = ensure(c, c->s_tiles, t.size() * sizeof(OrbxTileDesc))) != ORBX_OK) return st;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->s_tiles.p, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
   const size_t npx = (size_t)width * height;
   if ((st = ensure(c, c->s_u16, npx * 2)) != ORBX_OK) return st;
   if ((st = ensure(c, c->s_mask, (size_t)P.mask_words * 8)) != ORBX_OK) return st;
   OrbxFastParams fp{threshold, n, 0, 0};
-  HIPCHK(c, orbx_launch_fast_nms(c->stream, P, bm, 1, (const uint8_t*)c->s_img_a.p, fp,
-                                 (unsigned long long*)c->s_mask.p, (uint16_t*)c->s_u16.p, nullptr));
+  HIPCHK(c, orbx_launch_fast_nms(c->stream, (const OrbxTileDesc*)c->s_tiles.p, (int)t.size(),
+                                 (const uint8_t*)c->s_img_a.p, fp, (unsigned long long*)c->s_mask.p,
+                                 (uint16_t*)c->s_u16.p, nullptr));
   std::vector<uint16_t> h(npx);
   HIPCHK(c, hipMemcpyAsync(h.data(), c->s_u16.p, npx * 2, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -948,11 +1069,16 @@ int orbx_fast(orbx_ctx* c, const uint8_t* image, int width, int height, int stri
   OrbxBandMap bm;
   std::string why;
   if ((st = make_bandmap(P, &bm, &why)) != ORBX_OK) return fail(c, st, why);
+  std::vector<OrbxTileDesc> t;
+  build_fast_tiles(P, bm, 1, &t);
+  if ((st = ensure(c, c->s_tiles, t.size() * sizeof(OrbxTileDesc))) != ORBX_OK) return st;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->s_tiles.p, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
   if ((st = ensure(c, c->s_mask, (size_t)P.mask_words * 8)) != ORBX_OK) return st;
   OrbxFastParams fp{threshold, n, nms_window / 2, 0};
   // stage operator: exact totals are part of the contract -> no early exit
-  HIPCHK(c, orbx_launch_fast_nms(c->stream, P, bm, 1, (const uint8_t*)c->s_img_a.p, fp,
-                                 (unsigned long long*)c->s_mask.p, nullptr, nullptr));
+  HIPCHK(c, orbx_launch_fast_nms(c->stream, (const OrbxTileDesc*)c->s_tiles.p, (int)t.size(),
+                                 (const uint8_t*)c->s_img_a.p, fp, (unsigned long long*)c->s_mask.p, nullptr, nullptr));
   return compact_and_fetch(c, P, nfeatures, keypoints, count, total);
 }
 
@@ -1062,10 +1188,15 @@ static int blur_stage(orbx_ctx* c, const uint8_t* image, int width, int height, 
   if (st != ORBX_OK) return st;
   OrbxPlan P = flat_plan(width, height, 0);
   if ((st = ensure(c, c->s_img_b, (size_t)P.frame_bytes + 256)) != ORBX_OK) return st;
-  OrbxTileMap tm, tm2;
+  OrbxTileMap tm;
   make_tilemap(P, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &tm);
-  make_tilemap(P, ORBX_BLUR2_TW, 4 * orbx_blur2_rows_per_wave(), true, &tm2);
-  HIPCHK(c, launch_blur_auto(c->stream, P, tm, tm2, 1, (const uint8_t*)c->s_img_a.p, (uint8_t*)c->s_img_b.p, 0, kind));
+  std::vector<OrbxTileDesc> t;
+  build_frame_tiles(P, ORBX_BLUR2_TW, 4 * orbx_blur2_rows_per_wave(), false, &t);
+  if ((st = ensure(c, c->s_tiles, t.size() * sizeof(OrbxTileDesc))) != ORBX_OK) return st;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->s_tiles.p, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
+  HIPCHK(c, launch_blur_auto(c->stream, P, tm, (const OrbxTileDesc*)c->s_tiles.p, (int)t.size(), 1,
+                             (const uint8_t*)c->s_img_a.p, (uint8_t*)c->s_img_b.p, 0, kind));
   HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, c->s_img_b.p, pitch, width, height, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return ORBX_OK;
@@ -1140,7 +1271,8 @@ int orbx_build_pyramid_level(orbx_ctx* c, const uint8_t* image, int width, int h
   HIPCHK(c, hipMemcpy2DAsync(c->d_in, width, image, stride, width, height, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, launch_pyramid_auto(c, c->stream, 1, c->d_in, width, (size_t)width * height));
   if (blur_enabled(c))
-    HIPCHK(c, launch_blur_auto(c->stream, P, c->tm_blur, c->tm_blur2, 1, c->d_pyr, c->d_pyr_blur,
+    HIPCHK(c, launch_blur_auto(c->stream, P, c->tm_blur, c->d_tiles_blur2, c->blur2_tiles_count, 1, c->d_pyr,
+                               c->d_pyr_blur,
                                c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
   const OrbxLevel& L = P.L[level];
   HIPCHK(c, hipMemcpy2DAsync(dst, L.w, final_pyr(c) + L.img_off, L.pitch, L.w, L.h, hipMemcpyDeviceToHost,

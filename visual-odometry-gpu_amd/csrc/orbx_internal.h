@@ -55,6 +55,28 @@ struct OrbxBandMap {
   int32_t xprefix[ORBX_MAX_LEVELS + 1];  // prefix sums of tiles_x
 };
 
+// One 64-byte record per workgroup, read with a single scalar load: everything a
+// tile kernel needs to know about its tile.  Replaces the chains of dependent
+// scalar loads that decoding blockIdx through the plan / tile maps costs at the
+// start of every wave (~20 s_load round trips for the FAST kernel).
+//   FAST table   : one entry per (band, frame, level, tx) in band-major order;
+//                  img_off / mask_off include the frame.
+//   blur/pyramid : one entry per (level, tx, ty) of ONE frame (blockIdx.y = frame);
+//                  img_off is the level's offset inside a pyramid frame and
+//                  u0/u1/u2 carry xtab_off / ytab_off / win8 (pyramid only).
+struct OrbxTileDesc {
+  int32_t l, tx, ty, f;
+  int32_t w, h, pitch;
+  int32_t u0;  // FAST: cap            pyramid: xtab_off
+  int32_t u1;  // FAST: mask_wpr       pyramid: ytab_off
+  int32_t u2;  // FAST: tiles_x        pyramid: win8
+  uint32_t stat_index;  // FAST: first tile-row statistic of (frame, level)
+  uint32_t pad;
+  uint64_t img_off;   // bytes from the pyramid base
+  uint64_t mask_off;  // u64 words from the mask base (FAST)
+};
+static_assert(sizeof(OrbxTileDesc) == 64, "one 64-byte scalar load per workgroup");
+
 // 8-bit bilinear resize coefficient (OpenCV-style 11-bit fixed point)
 struct OrbxResizeTap {
   int32_t ofs;     // source index (clamped)
@@ -90,16 +112,19 @@ int orbx_blur2_rows_per_wave();  // 16 or 32; tile height of k_blur2 = 4x this
 hipError_t orbx_launch_pyramid(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
                                const uint8_t* d_in, int in_stride, size_t in_frame_stride,
                                const OrbxResizeTap* d_taps, uint8_t* d_pyr);
-hipError_t orbx_launch_pyramid2(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
-                                const uint8_t* d_in, int in_stride, size_t in_frame_stride,
+// d_tiles: tiles of ONE frame for 256 x 16 tiles
+hipError_t orbx_launch_pyramid2(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int w0,
+                                int h0, int n_frames, const uint8_t* d_in, int in_stride, size_t in_frame_stride,
                                 const OrbxResizeTap* d_taps, uint8_t* d_pyr);
 hipError_t orbx_launch_blur(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
                             const uint8_t* d_src, uint8_t* d_dst, int first_level, int kind);
-hipError_t orbx_launch_blur2(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
+// d_tiles: tiles of ONE frame for 248 x (4*rows_per_wave) strips
+hipError_t orbx_launch_blur2(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int n_frames,
                              const uint8_t* d_src, uint8_t* d_dst, int first_level);
-hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxPlan& plan, const OrbxBandMap& bm, int n_frames,
-                                const uint8_t* d_pyr, OrbxFastParams fp, unsigned long long* d_mask,
-                                uint16_t* d_scores_dbg, unsigned long long* d_row_stat);
+// d_tiles: n_tiles OrbxTileDesc in band-major order (orbx_api.cpp: build_fast_tiles)
+hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, const uint8_t* d_pyr,
+                                OrbxFastParams fp, unsigned long long* d_mask, uint16_t* d_scores_dbg,
+                                unsigned long long* d_row_stat);
 hipError_t orbx_launch_compact(hipStream_t s, const OrbxPlan& plan, int n_frames,
                                const unsigned long long* d_mask, orbx_keypoint* d_cand, int32_t* d_cand_count,
                                int32_t* d_cand_total, int need_total);

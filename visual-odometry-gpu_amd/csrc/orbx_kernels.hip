@@ -139,13 +139,18 @@ struct __attribute__((packed, aligned(1))) uint2_unaligned {
 };
 #define PYR2_ROWS 4  // output rows per wave
 
-__global__ __launch_bounds__(256) void k_pyramid2(OrbxPlan plan, OrbxTileMap tm, const uint8_t* __restrict__ in,
-                                                  int in_stride, size_t in_frame_stride,
-                                                  const OrbxResizeTap* __restrict__ taps,
+__global__ __launch_bounds__(256) void k_pyramid2(const OrbxTileDesc* __restrict__ tiles, int frame_bytes, int w0,
+                                                  int h0, const uint8_t* __restrict__ in, int in_stride,
+                                                  size_t in_frame_stride, const OrbxResizeTap* __restrict__ taps,
                                                   uint8_t* __restrict__ pyr) {
-  int l, tx, ty;
-  decode_tile(tm, plan.nlevels, l, tx, ty);
-  const OrbxLevel& L = plan.L[l];
+  const OrbxTileDesc d = tiles[blockIdx.x];  // one scalar load instead of decoding through the plan
+  struct {
+    int w, h, pitch, xtab_off, ytab_off, win8;
+  } L = {d.w, d.h, d.pitch, d.u0, d.u1, d.u2};
+  struct {
+    int w0, h0;
+  } plan = {w0, h0};
+  const int l = d.l, tx = d.tx, ty = d.ty;
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -154,8 +159,8 @@ __global__ __launch_bounds__(256) void k_pyramid2(OrbxPlan plan, OrbxTileMap tm,
   const int yb = ty * (4 * PYR2_ROWS) + wave * PYR2_ROWS;
   if (yb >= L.h) return;  // whole wave
   const int pitch = L.pitch, w = L.w;
-  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-      pyr + (size_t)f * plan.frame_bytes + L.img_off, 0, pitch * L.h, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout =
+      __builtin_amdgcn_make_buffer_rsrc(pyr + (size_t)f * frame_bytes + d.img_off, 0, pitch * L.h, 0x00020000);
   const uint32_t voff_st = x < pitch ? (uint32_t)x : 0xffffffffu;
   const int nvalid = w - x;
   const uint32_t vmask = nvalid >= 4 ? 0xffffffffu : nvalid <= 0 ? 0u : ((1u << (8 * nvalid)) - 1u);
@@ -395,11 +400,14 @@ __device__ __forceinline__ int reflect101_s(int p, int len) {
 }
 
 template <int RH>
-__global__ __launch_bounds__(256) void k_blur2(OrbxPlan plan, OrbxTileMap tm, const uint8_t* __restrict__ src,
-                                               uint8_t* __restrict__ dst, int first_level) {
-  int l, tx, ty;
-  decode_tile(tm, plan.nlevels, l, tx, ty);
-  const OrbxLevel& L = plan.L[l];
+__global__ __launch_bounds__(256) void k_blur2(const OrbxTileDesc* __restrict__ tiles, int frame_bytes,
+                                               const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                               int first_level) {
+  const OrbxTileDesc d = tiles[blockIdx.x];  // one scalar load instead of decoding through the plan
+  struct {
+    int w, h, pitch;
+  } L = {d.w, d.h, d.pitch};
+  const int l = d.l, tx = d.tx, ty = d.ty;
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: row math runs on the SALU
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(256) void k_blur2(OrbxPlan plan, OrbxTileMap tm, co
   // [0, pitch) use an out-of-range vector offset, so the hardware range check
   // zero-fills their loads and drops their stores -- no exec-mask juggling, no
   // 64-bit per-lane address arithmetic.
-  const size_t level_off = (size_t)f * plan.frame_bytes + L.img_off;
+  const size_t level_off = (size_t)f * frame_bytes + d.img_off;
   const __amdgpu_buffer_rsrc_t rin =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src) + level_off, 0, pitch * h, 0x00020000);
   const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(dst + level_off, 0, pitch * h, 0x00020000);
@@ -506,9 +514,8 @@ __device__ __forceinline__ bool has_run16(uint32_t m, int n) {
   return (acc & 0xffffu) != 0;
 }
 
-// Workgroup order is BAND-MAJOR: all tiles of tile-row 0 of every level of
-// every frame come first, then tile-row 1, ... (levels shrink with the level
-// index, so the levels present in band b are a prefix 0..n_b-1).  Together
+// Workgroup order (the tile table built by the host) is BAND-MAJOR: all tiles of
+// tile-row 0 of every level of every frame come first, then tile-row 1, ...  Together
 // with the per-(frame, level, tile-row) statistics below this lets a tile
 // prove that it cannot contribute: keypoints are kept in ROW-MAJOR order up
 // to `cap` (src/orb_cpu.cpp:108-110, src/orb.cpp:63), so once the tile rows
@@ -516,45 +523,6 @@ __device__ __forceinline__ bool has_run16(uint32_t m, int n) {
 // nothing in this tile can be among the first cap.  Such tiles write an empty
 // mask and exit.  The test only ever reads completed statistics, so it is
 // independent of dispatch order (a stale read just means "do the work").
-__device__ __forceinline__ void decode_band(const OrbxBandMap& bm, int nlevels, int n_frames, int& l, int& tx,
-                                            int& ty, int& f) {
-  const int id = blockIdx.x;
-  int b = 0;
-#pragma unroll 1
-  for (int i = 1; i < bm.nbands; i++)
-    if (id >= bm.band_begin[i] * n_frames) b = i;
-  const int rem = id - bm.band_begin[b] * n_frames;
-  int nl = 1;
-#pragma unroll 1
-  for (int i = 1; i < nlevels; i++)
-    if (bm.tiles_y[i] > b) nl = i + 1;
-  const int per_frame = bm.xprefix[nl];
-  f = rem / per_frame;
-  const int r2 = rem - f * per_frame;
-  l = 0;
-#pragma unroll 1
-  for (int i = 1; i < nl; i++)
-    if (r2 >= bm.xprefix[i]) l = i;
-  tx = r2 - bm.xprefix[l];
-  ty = b;
-}
-
-// ---------------------------------------------------------------------------
-// 3b. FAST + score + NMS, second generation (same results, ~3x fewer
-//     instructions per pixel).  Differences from k_fast_nms:
-//   * the 4-point pre-test runs on aligned DWORDS of the LDS tile -- 4 pixels
-//     per lane -- with packed-16-bit min/max: ">=3 of {N,E,S,W} brighter" <=>
-//     the 2nd smallest of the four >= Ip+t, ">=3 darker" <=> the 2nd largest
-//     <= Ip-t; both come out of one 8-op min/max network (v_pk_min/max_u16),
-//     the E/W/N/S/centre byte lanes are gathered with v_perm_b32;
-//   * all index arithmetic uses compile-time divisors (template on the NMS
-//     radius R);
-//   * NMS is evaluated only for corners (they are ~1% of the pixels): each
-//     corner compares itself with its (2R+1)^2 window in the LDS score tile
-//     and sets its bit in an LDS copy of the survivor mask (ds_or), which is
-//     then stored with one 8-byte store per tile row;
-//   * 8-byte global loads for the tile.
-
 static_assert(ORBX_FAST_TH == 64, "phase 5 assumes one wave per tile column of mask words");
 #define F2_IMG_PITCH 80                 // bytes: x0-8 .. x0+71
 #define F2_IMG_DW (F2_IMG_PITCH / 4)    // 20
@@ -583,7 +551,7 @@ __device__ __forceinline__ uint32_t pretest_pk(uint32_t ip, uint32_t a, uint32_t
 }
 
 template <int R, bool WRITE_SCORES>
-__global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxBandMap bm, int n_frames,
+__global__ __launch_bounds__(256) void k_fast_nms2(const OrbxTileDesc* __restrict__ tiles,
                                                    const uint8_t* __restrict__ pyr, OrbxFastParams fp,
                                                    u64* __restrict__ mask, uint16_t* __restrict__ scores_dbg,
                                                    u64* __restrict__ row_stat) {
@@ -598,23 +566,26 @@ __global__ __launch_bounds__(256) void k_fast_nms2(OrbxPlan plan, OrbxBandMap bm
   __shared__ int s_qn;
   __shared__ int s_skip;
 
-  int l, tx, ty, f;
-  decode_band(bm, plan.nlevels, n_frames, l, tx, ty, f);
-  const OrbxLevel& L = plan.L[l];
-  const uint8_t* img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
+  // everything about this tile in one 64-byte scalar load (band-major order, see above)
+  const OrbxTileDesc d = tiles[blockIdx.x];
+  struct {
+    int w, h, pitch, cap, mask_wpr;
+  } L = {d.w, d.h, d.pitch, d.u0, d.u1};
+  const int tx = d.tx, ty = d.ty, tiles_x = d.u2;
+  const uint8_t* img = pyr + d.img_off;
   const int tid = threadIdx.x;
   const int thr = fp.threshold;
   const int x0 = tx * TW, y0 = ty * TH;
   const int gy0 = y0 - 3 - R;
-  u64* mrow = mask + (size_t)f * plan.mask_words + L.mask_off;
-  u64* stat = row_stat ? row_stat + ((size_t)f * ORBX_MAX_LEVELS + l) * ORBX_MAX_BANDS : nullptr;
+  u64* mrow = mask + d.mask_off;
+  u64* stat = row_stat ? row_stat + d.stat_index : nullptr;
 
   // early exit: the tile rows above are complete and already hold >= cap survivors
   if (stat && ty > 0) {
     if (tid < 64) {
       u64 st = 0;
       if (tid < ty) st = __hip_atomic_load(&stat[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool complete = tid >= ty || (int)(st >> 32) == bm.tiles_x[l];
+      const bool complete = tid >= ty || (int)(st >> 32) == tiles_x;
       const u64 inc = __ballot(!complete);              // rows not yet complete
       const int k = inc ? __ffsll((long long)inc) - 1 : 64;  // first incomplete row
       const int surv = wave_sum(tid < k && tid < ty ? (int)(uint32_t)st : 0);
@@ -1869,12 +1840,13 @@ hipError_t orbx_launch_pyramid(hipStream_t s, const OrbxPlan& plan, const OrbxTi
   return ORBX_LAUNCH_CHECK();
 }
 
-// `tm` must be built for 256 x 16 tiles
-hipError_t orbx_launch_pyramid2(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
-                                const uint8_t* d_in, int in_stride, size_t in_frame_stride,
+hipError_t orbx_launch_pyramid2(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int w0,
+                                int h0, int n_frames, const uint8_t* d_in, int in_stride, size_t in_frame_stride,
                                 const OrbxResizeTap* d_taps, uint8_t* d_pyr) {
-  dim3 grid(tm.begin[plan.nlevels], n_frames);
-  hipLaunchKernelGGL(k_pyramid2, grid, dim3(256), 0, s, plan, tm, d_in, in_stride, in_frame_stride, d_taps, d_pyr);
+  if (n_tiles <= 0) return hipSuccess;
+  dim3 grid(n_tiles, n_frames);
+  hipLaunchKernelGGL(k_pyramid2, grid, dim3(256), 0, s, d_tiles, frame_bytes, w0, h0, d_in, in_stride,
+                     in_frame_stride, d_taps, d_pyr);
   return ORBX_LAUNCH_CHECK();
 }
 
@@ -1893,46 +1865,48 @@ int orbx_blur2_rows_per_wave() {
   return v;
 }
 
-// separable blur, register-streaming kernel; `tm` must be built for BL2_TW x BL2_TH tiles
-hipError_t orbx_launch_blur2(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
+// separable blur, register-streaming kernel; the tile table is built for 248 x (4*rows_per_wave) strips
+hipError_t orbx_launch_blur2(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int n_frames,
                              const uint8_t* d_src, uint8_t* d_dst, int first_level) {
-  dim3 grid(tm.begin[plan.nlevels], n_frames);
+  if (n_tiles <= 0) return hipSuccess;
+  dim3 grid(n_tiles, n_frames);
   if (orbx_blur2_rows_per_wave() == 32)
-    hipLaunchKernelGGL(k_blur2<32>, grid, dim3(256), 0, s, plan, tm, d_src, d_dst, first_level);
+    hipLaunchKernelGGL(k_blur2<32>, grid, dim3(256), 0, s, d_tiles, frame_bytes, d_src, d_dst, first_level);
   else
-    hipLaunchKernelGGL(k_blur2<16>, grid, dim3(256), 0, s, plan, tm, d_src, d_dst, first_level);
+    hipLaunchKernelGGL(k_blur2<16>, grid, dim3(256), 0, s, d_tiles, frame_bytes, d_src, d_dst, first_level);
   return ORBX_LAUNCH_CHECK();
 }
 
 template <int R>
-static void launch_fast2(dim3 grid, hipStream_t s, const OrbxPlan& plan, const OrbxBandMap& bm, int n_frames,
-                         const uint8_t* d_pyr, OrbxFastParams fp, unsigned long long* d_mask,
-                         uint16_t* d_scores_dbg, unsigned long long* d_row_stat) {
+static void launch_fast2(dim3 grid, hipStream_t s, const OrbxTileDesc* d_tiles, const uint8_t* d_pyr,
+                         OrbxFastParams fp, unsigned long long* d_mask, uint16_t* d_scores_dbg,
+                         unsigned long long* d_row_stat) {
   if (d_scores_dbg)
-    hipLaunchKernelGGL((k_fast_nms2<R, true>), grid, dim3(256), 0, s, plan, bm, n_frames, d_pyr, fp, d_mask,
-                       d_scores_dbg, d_row_stat);
+    hipLaunchKernelGGL((k_fast_nms2<R, true>), grid, dim3(256), 0, s, d_tiles, d_pyr, fp, d_mask, d_scores_dbg,
+                       d_row_stat);
   else
-    hipLaunchKernelGGL((k_fast_nms2<R, false>), grid, dim3(256), 0, s, plan, bm, n_frames, d_pyr, fp, d_mask,
-                       d_scores_dbg, d_row_stat);
+    hipLaunchKernelGGL((k_fast_nms2<R, false>), grid, dim3(256), 0, s, d_tiles, d_pyr, fp, d_mask, d_scores_dbg,
+                       d_row_stat);
 }
 
 // d_row_stat: n_frames * ORBX_MAX_LEVELS * ORBX_MAX_BANDS zeroed u64 (or NULL: no early exit)
-hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxPlan& plan, const OrbxBandMap& bm, int n_frames,
-                                const uint8_t* d_pyr, OrbxFastParams fp, unsigned long long* d_mask,
-                                uint16_t* d_scores_dbg, unsigned long long* d_row_stat) {
-  dim3 grid(bm.band_begin[bm.nbands] * n_frames);
+hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, const uint8_t* d_pyr,
+                                OrbxFastParams fp, unsigned long long* d_mask, uint16_t* d_scores_dbg,
+                                unsigned long long* d_row_stat) {
+  if (n_tiles <= 0) return hipSuccess;
+  dim3 grid(n_tiles);
   switch (fp.nms_radius) {
     case 0:
-      launch_fast2<0>(grid, s, plan, bm, n_frames, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
+      launch_fast2<0>(grid, s, d_tiles, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
       break;
     case 1:
-      launch_fast2<1>(grid, s, plan, bm, n_frames, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
+      launch_fast2<1>(grid, s, d_tiles, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
       break;
     case 2:
-      launch_fast2<2>(grid, s, plan, bm, n_frames, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
+      launch_fast2<2>(grid, s, d_tiles, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
       break;
     default:
-      launch_fast2<3>(grid, s, plan, bm, n_frames, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
+      launch_fast2<3>(grid, s, d_tiles, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
       break;
   }
   return ORBX_LAUNCH_CHECK();
