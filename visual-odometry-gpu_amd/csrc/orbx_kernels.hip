@@ -67,6 +67,21 @@ __device__ __forceinline__ int wave_sum(int v) {
          __builtin_amdgcn_readlane(v, 48);
 }
 
+// wave-wide inclusive prefix sum (lane i gets v_0 + ... + v_i) with DPP only
+// (GCN cross-lane scan: row_shr 1/2/3, row_shr 4 and 8 with bank masks, then
+// row_bcast 15 / 31 across the 16-lane rows)
+__device__ __forceinline__ int wave_scan_incl(int v) {
+  const int v0 = v;
+  v += __builtin_amdgcn_update_dpp(0, v0, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v0, 0x112 /*row_shr:2*/, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v0, 0x113 /*row_shr:3*/, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114 /*row_shr:4*/, 0xf, 0xe, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118 /*row_shr:8*/, 0xf, 0xc, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142 /*row_bcast:15*/, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143 /*row_bcast:31*/, 0xc, 0xf, false);
+  return v;
+}
+
 // ---------------------------------------------------------------------------
 // 1. pyramid: level 0 copy + fixed-point bilinear resize of every level >= 1
 //    straight from level 0 (src/orb.cpp:111-120).  Each thread produces 4
@@ -680,15 +695,10 @@ __global__ __launch_bounds__(256) void k_fast_nms2(const OrbxTileDesc* __restric
   {
     const int lane = tid & 63;
     const int cnt = __popc(cand_bits);
-    int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += t;
-    }
+    const int incl = wave_scan_incl(cnt);
     int wbase = 0;
     if (lane == 63) wbase = atomicAdd(&s_qn, incl);
-    wbase = __shfl(wbase, 63, 64);
+    wbase = __builtin_amdgcn_readlane(wbase, 63);
     int pos = wbase + incl - cnt;
     while (cand_bits) {
       const int bpos = __ffs(cand_bits) - 1;
@@ -806,12 +816,7 @@ __global__ __launch_bounds__(256) void k_compact(OrbxPlan plan, const u64* __res
     const int i = w0 + tid;
     u64 v = i < nwords ? m[i] : 0ull;
     const int c = __popcll(v);
-    int incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += t;
-    }
+    const int incl = wave_scan_incl(c);
     if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
     int woff = 0, tot = 0;
