@@ -496,15 +496,14 @@ const uint8_t* final_pyr(const orbx_ctx* c);
 // FAST + NMS of the batched path.  Tiles that provably cannot contribute to the
 // first `cap` row-major survivors exit early (see decode_band in the kernels);
 // ORBX_FAST_EARLY=0 disables that (every tile does the full work).
-hipError_t launch_fast_whole(orbx_ctx* c, hipStream_t s, int n, OrbxFastParams fp) {
+hipError_t launch_fast_whole(orbx_ctx* c, hipStream_t s, int n, OrbxFastParams fp, bool stats_zeroed = false) {
   if (c->fast_tiles_n != n) return hipErrorInvalidValue;  // ensure_fast_tiles() must have run
   static const int early_env = [] {
     const char* e = getenv("ORBX_FAST_EARLY");
     return e ? atoi(e) : 1;
   }();
-  unsigned long long* stat = nullptr;
-  if (early_env && c->fast_early) {
-    stat = c->d_row_stat;
+  unsigned long long* stat = (early_env && c->fast_early) ? c->d_row_stat : nullptr;
+  if (stat && !stats_zeroed) {
     hipError_t e = hipMemsetAsync(stat, 0, (size_t)n * ORBX_MAX_LEVELS * ORBX_MAX_BANDS * 8, s);
     if (e != hipSuccess) return e;
   }
@@ -546,6 +545,9 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
     if (tm == 1 || (tm == 2 && roofline_edge)) return hipEventRecord(evs[slot], s);
     return hipSuccess;
   };
+  // tile-row statistics of the FAST early exit: zeroed up front so that the events
+  // around the FAST stage bracket the kernel alone
+  HIPCHK(c, hipMemsetAsync(c->d_row_stat, 0, (size_t)n * ORBX_MAX_LEVELS * ORBX_MAX_BANDS * 8, s));
   HIPCHK(c, mark(0, false));
   HIPCHK(c, launch_pyramid_auto(c, s, n, d_frames, row_stride, frame_stride));
   HIPCHK(c, mark(1, true));
@@ -555,7 +557,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   HIPCHK(c, mark(2, true));
   OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2, fast_ablate()};
   if ((st = ensure_fast_tiles(c, n)) != ORBX_OK) return st;
-  HIPCHK(c, launch_fast_whole(c, s, n, fp));
+  HIPCHK(c, launch_fast_whole(c, s, n, fp, true));
   HIPCHK(c, mark(3, true));
   HIPCHK(c, orbx_launch_compact(s, P, n, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total, 0));
   HIPCHK(c, mark(4, false));
