@@ -954,54 +954,64 @@ __device__ __forceinline__ float harris_any(const uint8_t* img, int w, int h, in
 // order, which reproduces the oracle's (i,j) row-major summation bit for bit.
 // 8x more waves than thread-per-keypoint (the old kernel had 2 waves per SIMD)
 // and a ~6x shorter dependent chain per keypoint.
-template <int K>
+// RPL window rows per lane, G = lanes per keypoint (power of two >= ceil(K/RPL)).
+template <int K, int RPL, int G>
 __device__ __forceinline__ float harris_row_group(const uint8_t* img, int pitch, int x, int y,
                                                   const float* __restrict__ g, float kk, int sub) {
-  constexpr int r = K / 2, P = K + 2;
-  const int row_i = sub < K ? sub : K - 1;  // idle lanes shadow the last row (their sums are never used)
+  constexpr int r = K / 2, P = K + 2, NR = RPL + 2;  // NR patch rows feed RPL window rows
+  constexpr int NL = (K + RPL - 1) / RPL;            // lanes that own rows
+  const int row0 = (sub < NL ? sub : NL - 1) * RPL;  // idle lanes shadow the last group (sums never used)
   const int xs = x - r - 1;
   const int a0 = xs & ~3, off = xs - a0;
-  float p[3][P];
+  float p[NR][P];
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
-    const uint32_t* row = reinterpret_cast<const uint32_t*>(img + (size_t)(y - r - 1 + row_i + i) * pitch + a0);
+  for (int i = 0; i < NR; i++) {
+    // rows past the window (last lane when K is not a multiple of RPL) repeat the last patch row
+    const int pr = min(row0 + i, P - 1);
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(img + (size_t)(y - r - 1 + pr) * pitch + a0);
     const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];
     const uint32_t q[3] = {__builtin_amdgcn_alignbyte(d1, d0, off), __builtin_amdgcn_alignbyte(d2, d1, off),
                            d2 >> (8 * off)};
 #pragma unroll
     for (int j = 0; j < P; j++) p[i][j] = (float)((q[j >> 2] >> (8 * (j & 3))) & 0xffu);
   }
-  float pa[K], pb[K], pc[K];
-  {
-    float vs[P], h0[K], h2[K];
+  float hs[NR][K];
 #pragma unroll
-    for (int j = 0; j < P; j++) vs[j] = p[0][j] + 2.0f * p[1][j] + p[2][j];
+  for (int i = 0; i < NR; i++)
+#pragma unroll
+    for (int j = 0; j < K; j++) hs[i][j] = p[i][j] + 2.0f * p[i][j + 1] + p[i][j + 2];
+  float pa[RPL][K], pb[RPL][K], pc[RPL][K];
+#pragma unroll
+  for (int w = 0; w < RPL; w++) {
+    float vs[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) vs[j] = p[w][j] + 2.0f * p[w + 1][j] + p[w + 2][j];
+    const int wr = min(row0 + w, K - 1);
 #pragma unroll
     for (int j = 0; j < K; j++) {
-      h0[j] = p[0][j] + 2.0f * p[0][j + 1] + p[0][j + 2];
-      h2[j] = p[2][j] + 2.0f * p[2][j + 1] + p[2][j + 2];
-    }
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-      const float gx = vs[j + 2] - vs[j], gy = h2[j] - h0[j];
-      const float wgt = g[row_i * K + j];
-      pa[j] = __fmul_rn(__fmul_rn(gx, gx), wgt);
-      pc[j] = __fmul_rn(__fmul_rn(gy, gy), wgt);
-      pb[j] = __fmul_rn(__fmul_rn(gx, gy), wgt);
+      const float gx = vs[j + 2] - vs[j], gy = hs[w + 2][j] - hs[w][j];
+      const float wgt = g[wr * K + j];
+      pa[w][j] = __fmul_rn(__fmul_rn(gx, gx), wgt);
+      pc[w][j] = __fmul_rn(__fmul_rn(gy, gy), wgt);
+      pb[w][j] = __fmul_rn(__fmul_rn(gx, gy), wgt);
     }
   }
   float a = 0.f, b = 0.f, c = 0.f;
 #pragma unroll
-  for (int rr = 0; rr < K; rr++) {
+  for (int rr = 0; rr < NL; rr++) {
     if (sub == rr) {
 #pragma unroll
-      for (int j = 0; j < K; j++) {
-        a = __fadd_rn(a, pa[j]);
-        c = __fadd_rn(c, pc[j]);
-        b = __fadd_rn(b, pb[j]);
-      }
+      for (int w = 0; w < RPL; w++)
+        if (rr * RPL + w < K) {
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            a = __fadd_rn(a, pa[w][j]);
+            c = __fadd_rn(c, pc[w][j]);
+            b = __fadd_rn(b, pb[w][j]);
+          }
+        }
     }
-    if (rr + 1 < K) {  // hand the running sums to the next lane of the group
+    if (rr + 1 < NL) {  // hand the running sums to the next lane of the group
       const float an = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x111, 0xf, 0xf, true));
       const float bn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x111, 0xf, 0xf, true));
       const float cn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), 0x111, 0xf, 0xf, true));
@@ -1014,11 +1024,11 @@ __device__ __forceinline__ float harris_row_group(const uint8_t* img, int pitch,
   }
   const float det = __fsub_rn(__fmul_rn(a, c), __fmul_rn(b, b));
   const float trace = __fadd_rn(a, c);
-  return __fsub_rn(det, __fmul_rn(__fmul_rn(kk, trace), trace));  // valid in lane sub == K-1
+  return __fsub_rn(det, __fmul_rn(__fmul_rn(kk, trace), trace));  // valid in lane sub == NL-1
 }
 
-// one keypoint per 8-lane group; result returned in every lane of the group's
-// lane `K-1` (fast path) or lane 0 (generic path); `writer` tells which
+// one keypoint per G-lane group; the result is valid in the lane `writer` says
+template <int RPL, int G>
 __device__ __forceinline__ float harris_group(const uint8_t* img, int w, int h, int pitch, int x, int y,
                                               const float* __restrict__ g, int K, float kk, int sub, bool active,
                                               bool& writer) {
@@ -1031,10 +1041,18 @@ __device__ __forceinline__ float harris_group(const uint8_t* img, int w, int h, 
   if (any_fast) {
     const int xx = (active && fast) ? x : m, yy = (active && fast) ? y : m;  // harmless in-image stand-in
     float v = 0.f;
-    if (K == 7) v = harris_row_group<7>(img, pitch, xx, yy, g, kk, sub);
-    else if (K == 5) v = harris_row_group<5>(img, pitch, xx, yy, g, kk, sub);
-    else v = harris_row_group<3>(img, pitch, xx, yy, g, kk, sub);
-    if (active && fast && sub == K - 1) {
+    int last = 0;
+    if (K == 7) {
+      v = harris_row_group<7, RPL, G>(img, pitch, xx, yy, g, kk, sub);
+      last = (7 + RPL - 1) / RPL - 1;
+    } else if (K == 5) {
+      v = harris_row_group<5, RPL, G>(img, pitch, xx, yy, g, kk, sub);
+      last = (5 + RPL - 1) / RPL - 1;
+    } else {
+      v = harris_row_group<3, RPL, G>(img, pitch, xx, yy, g, kk, sub);
+      last = (3 + RPL - 1) / RPL - 1;
+    }
+    if (active && fast && sub == last) {
       res = v;
       writer = true;
     }
@@ -1046,12 +1064,15 @@ __device__ __forceinline__ float harris_group(const uint8_t* img, int w, int h, 
   return res;
 }
 
+// G lanes per keypoint: G = 8 -> one window row per lane, G = 4 -> two rows per lane
+template <int G>
 __global__ __launch_bounds__(256) void k_harris2(OrbxPlan plan, const uint8_t* __restrict__ pyr,
                                                  const orbx_keypoint* __restrict__ cand,
                                                  const int32_t* __restrict__ cand_count,
                                                  const float* __restrict__ gauss, int K, float kk,
                                                  float* __restrict__ resp) {
-  const int j = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+  constexpr int RPL = G == 8 ? 1 : 2;
+  const int j = blockIdx.x * (256 / G) + threadIdx.x / G, sub = threadIdx.x & (G - 1);
   const int f = blockIdx.y;
   int l = 0;
   for (int i = 1; i < plan.nlevels; i++)
@@ -1063,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_harris2(OrbxPlan plan, const uint8_t* _
   // lanes of one wave may sit on different levels: the level image is per lane
   const uint8_t* img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
   bool writer;
-  const float v = harris_group(img, L.w, L.h, L.pitch, kp.x, kp.y, gauss, K, kk, sub, active, writer);
+  const float v = harris_group<RPL, G>(img, L.w, L.h, L.pitch, kp.x, kp.y, gauss, K, kk, sub, active, writer);
   if (writer) resp[(size_t)f * plan.cand_total + j] = v;
 }
 
@@ -1071,12 +1092,13 @@ __global__ __launch_bounds__(256) void k_harris2_flat(const uint8_t* __restrict_
                                                       const orbx_keypoint* __restrict__ kps, int nkp,
                                                       const float* __restrict__ gauss, int K, float kk,
                                                       float* __restrict__ resp) {
+  constexpr int G = 8, RPL = 1;
   const int j = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
   const bool active = j < nkp;
   orbx_keypoint kp = {4, 4};
   if (active) kp = kps[j];
   bool writer;
-  const float v = harris_group(img, w, h, pitch, kp.x, kp.y, gauss, K, kk, sub, active, writer);
+  const float v = harris_group<RPL, G>(img, w, h, pitch, kp.x, kp.y, gauss, K, kk, sub, active, writer);
   if (writer) resp[j] = v;
 }
 
@@ -1942,9 +1964,13 @@ hipError_t orbx_launch_harris(hipStream_t s, const OrbxPlan& plan, int n_frames,
     dim3 grid((plan.cand_total + 255) / 256, n_frames);
     hipLaunchKernelGGL(k_harris, grid, dim3(256), 0, s, plan, d_pyr, d_cand, d_cand_count, d_gauss, window, k,
                        d_resp);
+  } else if (impl == 4) {  // two window rows per lane: measured slower than both (47 us), kept for A/B
+    dim3 grid((plan.cand_total + 63) / 64, n_frames);
+    hipLaunchKernelGGL(k_harris2<4>, grid, dim3(256), 0, s, plan, d_pyr, d_cand, d_cand_count, d_gauss, window, k,
+                       d_resp);
   } else {
     dim3 grid((plan.cand_total + 31) / 32, n_frames);
-    hipLaunchKernelGGL(k_harris2, grid, dim3(256), 0, s, plan, d_pyr, d_cand, d_cand_count, d_gauss, window, k,
+    hipLaunchKernelGGL(k_harris2<8>, grid, dim3(256), 0, s, plan, d_pyr, d_cand, d_cand_count, d_gauss, window, k,
                        d_resp);
   }
   return ORBX_LAUNCH_CHECK();
