@@ -97,6 +97,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true",
                     help="do not record per-stage HIP events inside the timed region (diagnostic)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl == RCCL; gloo only to rehearse N>1 on a one-GPU box)")
+    ap.add_argument("--all-ranks-on-device0", action="store_true",
+                    help="rehearsal: every rank uses GPU 0 (needs --dist-backend gloo)")
     ap.add_argument("--only-timed", action="store_true",
                     help="skip every extra pass (full-work FAST, D2H, single-frame, matcher): for rocprofv3 runs whose "
                          "per-kernel averages must describe the timed configuration only")
@@ -115,9 +119,14 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if args.all_ranks_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     pkg = importlib.import_module("visual-odometry-gpu_amd")
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
@@ -143,7 +152,7 @@ def main():
     d_frames = torch.from_numpy(frames).cuda()
     torch.cuda.synchronize()
 
-    grp = pkg.shard.Group(world, device=torch.device("cuda", local_rank))
+    grp = pkg.shard.Group(world, device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None)
 
     def barrier():
         torch.cuda.synchronize()
