@@ -67,7 +67,7 @@ struct orbx_ctx {
   // geometry for the current frame size, and for the largest size (capacity)
   OrbxPlan plan{};
   OrbxPlan plan_max{};
-  OrbxTileMap tm_pyr{}, tm_pyr2{}, tm_blur{}, tm_blur2{};
+  OrbxTileMap tm_blur{};  // 5x5 /273 variant (LDS tile kernel)
   OrbxBandMap bm_fast{};
   unsigned long long* d_row_stat = nullptr;
   // per-workgroup tile descriptor tables (see OrbxTileDesc)
@@ -433,10 +433,7 @@ int set_plan(orbx_ctx* c, int w, int h) {
   HIPCHK(c, hipMemcpy(c->d_taps, c->h_taps.data(), c->h_taps.size() * sizeof(OrbxResizeTap),
                       hipMemcpyHostToDevice));
   c->plan = plan;
-  make_tilemap(plan, ORBX_PYR_TW, ORBX_PYR_TH, true, &c->tm_pyr);
-  make_tilemap(plan, ORBX_PYR2_TW, ORBX_PYR2_TH, true, &c->tm_pyr2);
   make_tilemap(plan, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &c->tm_blur);
-  make_tilemap(plan, ORBX_BLUR2_TW, 4 * orbx_blur2_rows_per_wave(), true, &c->tm_blur2);
   if ((st = make_bandmap(plan, &c->bm_fast, &why)) != ORBX_OK) return fail(c, st, why);
   {
     std::vector<OrbxTileDesc> t;
@@ -469,15 +466,8 @@ int ensure_fast_tiles(orbx_ctx* c, int n) {
   return ORBX_OK;
 }
 
-// ORBX_PYR_IMPL=1 forces the first-generation pyramid kernel (A/B timing)
 hipError_t launch_pyramid_auto(orbx_ctx* c, hipStream_t s, int n, const uint8_t* d_in, int in_stride,
                                size_t in_frame_stride) {
-  static const int impl = [] {
-    const char* e = getenv("ORBX_PYR_IMPL");
-    return e ? atoi(e) : 2;
-  }();
-  if (impl == 1)
-    return orbx_launch_pyramid(s, c->plan, c->tm_pyr, n, d_in, in_stride, in_frame_stride, c->d_taps, c->d_pyr);
   return orbx_launch_pyramid2(s, c->d_tiles_pyr2, c->pyr2_tiles_count, c->plan.frame_bytes, c->plan.w0, c->plan.h0, n,
                               d_in, in_stride, in_frame_stride, c->d_taps, c->d_pyr);
 }

@@ -98,10 +98,7 @@ struct OrbxFastParams {
 #define ORBX_BLUR2_TW 248
 #define ORBX_BLUR2_TH 64
 int orbx_blur2_rows_per_wave();  // 16 or 32; tile height of k_blur2 = 4x this
-// tile geometry of the pyramid kernel (each thread: 4 px)
-#define ORBX_PYR_TW 256
-#define ORBX_PYR_TH 4
-// k_pyramid2: a wave owns 256 x 4 pixels, a workgroup 256 x 16
+// pyramid kernel: a wave owns 256 x 4 pixels, a workgroup 256 x 16
 #define ORBX_PYR2_TW 256
 #define ORBX_PYR2_TH 16
 
@@ -109,9 +106,6 @@ int orbx_blur2_rows_per_wave();  // 16 or 32; tile height of k_blur2 = 4x this
 
 // ---- launchers (orbx_kernels.hip) ------------------------------------------
 // All take the stream explicitly and never synchronise or allocate.
-hipError_t orbx_launch_pyramid(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
-                               const uint8_t* d_in, int in_stride, size_t in_frame_stride,
-                               const OrbxResizeTap* d_taps, uint8_t* d_pyr);
 // d_tiles: tiles of ONE frame for 256 x 16 tiles
 hipError_t orbx_launch_pyramid2(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int w0,
                                 int h0, int n_frames, const uint8_t* d_in, int in_stride, size_t in_frame_stride,

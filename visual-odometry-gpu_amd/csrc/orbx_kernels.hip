@@ -84,65 +84,10 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 
 // ---------------------------------------------------------------------------
 // 1. pyramid: level 0 copy + fixed-point bilinear resize of every level >= 1
-//    straight from level 0 (src/orb.cpp:111-120).  Each thread produces 4
-//    horizontally adjacent pixels and stores one dword.
-__global__ __launch_bounds__(256) void k_pyramid(OrbxPlan plan, OrbxTileMap tm, const uint8_t* __restrict__ in,
-                                                 int in_stride, size_t in_frame_stride,
-                                                 const OrbxResizeTap* __restrict__ taps,
-                                                 uint8_t* __restrict__ pyr) {
-  int l, tx, ty;
-  decode_tile(tm, plan.nlevels, l, tx, ty);
-  const OrbxLevel& L = plan.L[l];
-  const int f = blockIdx.y;
-  const uint8_t* src = in + (size_t)f * in_frame_stride;
-  uint8_t* dst = pyr + (size_t)f * plan.frame_bytes + L.img_off;
-  const int x = tx * ORBX_PYR_TW + (threadIdx.x & 63) * 4;
-  const int y = ty * ORBX_PYR_TH + (threadIdx.x >> 6);
-  if (y >= L.h || x >= L.pitch) return;
-  uint32_t out = 0;
-  if (l == 0) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int xx = x + k;
-      const uint32_t v = xx < L.w ? src[(size_t)y * in_stride + xx] : 0u;
-      out |= v << (8 * k);
-    }
-  } else {
-    const OrbxResizeTap ty_ = taps[L.ytab_off + y];
-    int sy0 = ty_.ofs, sy1 = ty_.ofs + 1;
-    sy0 = min(max(sy0, 0), plan.h0 - 1);
-    sy1 = min(max(sy1, 0), plan.h0 - 1);
-    const uint8_t* S0 = src + (size_t)sy0 * in_stride;
-    const uint8_t* S1 = src + (size_t)sy1 * in_stride;
-    const int b0 = ty_.c0, b1 = ty_.c1;
-    // the four x taps of this thread: 32 contiguous, 32-byte aligned bytes of the
-    // table (x tables are padded to a multiple of 4 entries) -> two 16-byte loads
-    const uint4* tp = reinterpret_cast<const uint4*>(taps + L.xtab_off + x);
-    const uint4 t01 = tp[0], t23 = tp[1];
-    const uint32_t ofs[4] = {t01.x, t01.z, t23.x, t23.z};
-    const uint32_t cc[4] = {t01.y, t01.w, t23.y, t23.w};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (x + k < L.w) {
-        // ofs <= w0-2 always (host table), so one unaligned 16-bit load fetches
-        // src[ofs] (low byte) and src[ofs+1] (high byte)
-        const uint32_t p0 = *reinterpret_cast<const u16_unaligned*>(S0 + ofs[k]);
-        const uint32_t p1 = *reinterpret_cast<const u16_unaligned*>(S1 + ofs[k]);
-        const int c0 = (int)(cc[k] & 0xffffu), c1 = (int)(cc[k] >> 16);
-        const int r0 = (int)(p0 & 0xffu) * c0 + (int)(p0 >> 8) * c1;
-        const int r1 = (int)(p1 & 0xffu) * c0 + (int)(p1 >> 8) * c1;
-        const uint32_t v = (uint32_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
-        out |= v << (8 * k);
-      }
-    }
-  }
-  *reinterpret_cast<uint32_t*>(dst + (size_t)y * L.pitch + x) = out;
-}
-
-// ---------------------------------------------------------------------------
-// 1b. pyramid, second generation.  The first kernel is latency-bound: 416k
-//     short waves, each with two dependent memory round trips (tap table ->
-//     pixel gathers).  Here a wave owns 256 x 4 output pixels: the row index
+//    straight from level 0 (src/orb.cpp:111-120).  (A first version with one
+//    thread per 4 pixels was latency-bound: 416k short waves, each with two
+//    dependent memory round trips, tap table -> pixel gathers; 206 us per batch.)
+//    Here a wave owns 256 x 4 output pixels: the row index
 //     is wave-uniform, so the y tap and the two source-row bases are scalar
 //     loads / SGPR addresses; the four x taps of a lane are loaded once and
 //     reused for four rows; all 32 pixel-pair gathers of a lane are issued
@@ -1415,50 +1360,6 @@ __device__ __forceinline__ void describe_wave(const DescJob& jb, DescLds& lds, i
   }
 }
 
-__global__ __launch_bounds__(256) void k_describe(OrbxPlan plan, const uint8_t* __restrict__ pyr, int patch_size,
-                                                  const int32_t* __restrict__ out_count,
-                                                  const orbx_keypoint* __restrict__ out_lkp,
-                                                  const int32_t* __restrict__ out_level,
-                                                  orbx_keypoint* __restrict__ out_kp,
-                                                  float* __restrict__ out_angle,
-                                                  orbx_descriptor* __restrict__ out_desc) {
-  __shared__ __attribute__((aligned(16))) DescLds s_lds[4];
-  const int f = blockIdx.y, wave = threadIdx.x >> 6;
-  const int slot = blockIdx.x * 4 + wave;
-  const int count = out_count[f];
-  DescJob jb;
-  jb.valid = slot < count;
-  int l = 0;
-  orbx_keypoint kp = {0, 0};
-  if (jb.valid) {
-    kp = out_lkp[(size_t)f * plan.out_cap + slot];
-    l = out_level[(size_t)f * plan.out_cap + slot];
-  }
-  const OrbxLevel& L = plan.L[l];
-  jb.img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
-  jb.w = L.w;
-  jb.h = L.h;
-  jb.pitch = L.pitch;
-  jb.x = kp.x;
-  jb.y = kp.y;
-  float angle;
-  u64 d[4];
-  describe_wave(jb, s_lds[wave], patch_size, false, 0.0f, true, angle, d);
-  if (jb.valid && lane_id() == 0) {
-    const size_t o = (size_t)f * plan.out_cap + slot;
-    out_angle[o] = angle;
-    orbx_keypoint g;  // kp.x *= scale on int (src/orb.cpp:94-98)
-    g.x = (int)__fmul_rn((float)kp.x, L.scale);
-    g.y = (int)__fmul_rn((float)kp.y, L.scale);
-    out_kp[o] = g;
-    u64* dd = reinterpret_cast<u64*>(out_desc + o);
-    dd[0] = d[0];
-    dd[1] = d[1];
-    dd[2] = d[2];
-    dd[3] = d[3];
-  }
-}
-
 // ---------------------------------------------------------------------------
 // 7b. orientation + BRIEF, second generation: a workgroup owns 16 keypoints.
 //   The per-keypoint transcendental work (restated atan2f, sinf, cosf: ~350
@@ -1859,14 +1760,6 @@ __global__ __launch_bounds__(256) void k_conv2d(const uint8_t* __restrict__ img,
 
 #define ORBX_LAUNCH_CHECK() hipGetLastError()
 
-hipError_t orbx_launch_pyramid(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
-                               const uint8_t* d_in, int in_stride, size_t in_frame_stride,
-                               const OrbxResizeTap* d_taps, uint8_t* d_pyr) {
-  dim3 grid(tm.begin[plan.nlevels], n_frames);
-  hipLaunchKernelGGL(k_pyramid, grid, dim3(256), 0, s, plan, tm, d_in, in_stride, in_frame_stride, d_taps, d_pyr);
-  return ORBX_LAUNCH_CHECK();
-}
-
 hipError_t orbx_launch_pyramid2(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int w0,
                                 int h0, int n_frames, const uint8_t* d_in, int in_stride, size_t in_frame_stride,
                                 const OrbxResizeTap* d_taps, uint8_t* d_pyr) {
@@ -1996,19 +1889,9 @@ hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frame
                                 const int32_t* d_out_level, orbx_keypoint* d_out_kp, float* d_out_angle,
                                 orbx_descriptor* d_out_desc) {
   if (plan.out_cap <= 0) return hipSuccess;
-  static const int impl = [] {
-    const char* e = getenv("ORBX_DESC_IMPL");  // 1 = first-generation kernel (A/B timing)
-    return e ? atoi(e) : 2;
-  }();
-  if (impl == 1) {
-    dim3 grid((plan.out_cap + 3) / 4, n_frames);
-    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_out_count, d_out_lkp,
-                       d_out_level, d_out_kp, d_out_angle, d_out_desc);
-  } else {
-    dim3 grid((plan.out_cap + DESC_KPB - 1) / DESC_KPB, n_frames);
-    hipLaunchKernelGGL(k_describe2, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_out_count, d_out_lkp,
-                       d_out_level, d_out_kp, d_out_angle, d_out_desc);
-  }
+  dim3 grid((plan.out_cap + DESC_KPB - 1) / DESC_KPB, n_frames);
+  hipLaunchKernelGGL(k_describe2, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_out_count, d_out_lkp,
+                     d_out_level, d_out_kp, d_out_angle, d_out_desc);
   return ORBX_LAUNCH_CHECK();
 }
 
