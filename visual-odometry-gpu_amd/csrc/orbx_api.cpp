@@ -297,12 +297,13 @@ int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string
     if (quota < 0) quota = 0;
     L.quota = quota;
     L.cap = p.select_mode == ORBX_SELECT_HARRIS ? 2 * quota : quota;  // src/orb.cpp:63
-    if (p.select_mode == ORBX_SELECT_HARRIS && L.cap > ORBX_MAX_SELECT) {
+    if (L.cap > ORBX_MAX_SELECT) {
       *why = "per-level FAST cap " + std::to_string(L.cap) + " exceeds ORBX_MAX_SELECT";
       return ORBX_ERR_UNSUPPORTED;
     }
     L.cand_off = cand_off;
     cand_off += L.cap;
+    L.out_off = out_cap;
     out_cap += quota;
     L.scale = level_scale(p.scale_factor, l);
     // x table first (padded to a multiple of 4 entries = 32 bytes so that a thread's
@@ -549,21 +550,17 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   if ((st = ensure_fast_tiles(c, n)) != ORBX_OK) return st;
   HIPCHK(c, launch_fast_whole(c, s, n, fp, true));
   HIPCHK(c, mark(3, true));
-  HIPCHK(c, orbx_launch_compact(s, P, n, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total, 0));
-  HIPCHK(c, mark(4, false));
-  if (c->p.select_mode == ORBX_SELECT_HARRIS)
-    HIPCHK(c, orbx_launch_harris(s, P, n, final_pyr(c), c->d_cand, c->d_cand_count, c->d_gauss,
-                                 c->p.harris_window, c->p.harris_k, c->d_resp));
+  HIPCHK(c, mark(4, false));  // (compaction, Harris and selection are one kernel: its time is the "select" slot)
   HIPCHK(c, mark(5, false));
   // result block sections are laid out for (n, pool slot capacity)
   c->out_layout = make_out_layout(n, P.out_cap > 0 ? P.out_cap : 1);
   const OutLayout& o = c->out_layout;
-  HIPCHK(c, orbx_launch_select(s, P, n, c->p.select_mode, c->d_cand, c->d_cand_count, c->d_resp,
-                               (orbx_keypoint*)(c->d_out + o.lkp), (float*)(c->d_out + o.resp),
-                               (int32_t*)(c->d_out + o.level), (int32_t*)(c->d_out + o.counts)));
+  HIPCHK(c, orbx_launch_level_select(s, P, n, c->p.select_mode, c->d_mask, final_pyr(c), c->d_gauss,
+                                     c->p.harris_window, c->p.harris_k, c->d_cand, c->d_resp, c->d_cand_count));
   HIPCHK(c, mark(6, false));
-  HIPCHK(c, orbx_launch_describe(s, P, n, final_pyr(c), c->p.patch_size, (const int32_t*)(c->d_out + o.counts),
-                                 (const orbx_keypoint*)(c->d_out + o.lkp), (const int32_t*)(c->d_out + o.level),
+  HIPCHK(c, orbx_launch_describe(s, P, n, final_pyr(c), c->p.patch_size, c->d_cand_count, c->d_cand, c->d_resp,
+                                 (int32_t*)(c->d_out + o.counts), (orbx_keypoint*)(c->d_out + o.lkp),
+                                 (float*)(c->d_out + o.resp), (int32_t*)(c->d_out + o.level),
                                  (orbx_keypoint*)(c->d_out + o.kp), (float*)(c->d_out + o.angle),
                                  (orbx_descriptor*)(c->d_out + o.desc)));
   HIPCHK(c, mark(7, false));

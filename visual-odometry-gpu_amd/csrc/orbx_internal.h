@@ -26,6 +26,7 @@ struct OrbxLevel {
   int32_t xtab_off;  // first entry of this level's resize x-table
   int32_t ytab_off;  // first entry of this level's resize y-table
   float scale;       // (float)pow(scaleFactor, l)  src/orb.cpp:95
+  int32_t out_off;   // first STATIC selection slot of this level = sum of the lower levels' quotas
   int32_t win8;      // resize: the 4 source pairs of any aligned group of 4 outputs fit one 8-byte window
 };
 
@@ -102,7 +103,7 @@ int orbx_blur2_rows_per_wave();  // 16 or 32; tile height of k_blur2 = 4x this
 #define ORBX_PYR2_TW 256
 #define ORBX_PYR2_TH 16
 
-#define ORBX_MAX_SELECT 8192  // largest per-level FAST cap the select kernel ranks in LDS (8 B per candidate)
+#define ORBX_MAX_SELECT 4096  // largest per-level FAST cap the selection kernel holds in LDS (16 B per candidate)
 
 // ---- launchers (orbx_kernels.hip) ------------------------------------------
 // All take the stream explicitly and never synchronise or allocate.
@@ -132,9 +133,15 @@ hipError_t orbx_launch_select(hipStream_t s, const OrbxPlan& plan, int n_frames,
                               const orbx_keypoint* d_cand, const int32_t* d_cand_count, const float* d_resp,
                               orbx_keypoint* d_out_lkp, float* d_out_resp, int32_t* d_out_level,
                               int32_t* d_out_count);
+// fused compaction + Harris + selection, one workgroup per (level, frame)
+hipError_t orbx_launch_level_select(hipStream_t s, const OrbxPlan& plan, int n_frames, int mode,
+                                    const unsigned long long* d_mask, const uint8_t* d_pyr, const float* d_gauss,
+                                    int window, float k, orbx_keypoint* d_sel_lkp, float* d_sel_resp,
+                                    int32_t* d_sel_count);
 hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frames, const uint8_t* d_pyr,
-                                int patch_size, const int32_t* d_out_count, const orbx_keypoint* d_out_lkp,
-                                const int32_t* d_out_level, orbx_keypoint* d_out_kp, float* d_out_angle,
+                                int patch_size, const int32_t* d_sel_count, const orbx_keypoint* d_sel_lkp,
+                                const float* d_sel_resp, int32_t* d_out_count, orbx_keypoint* d_out_lkp,
+                                float* d_out_resp, int32_t* d_out_level, orbx_keypoint* d_out_kp, float* d_out_angle,
                                 orbx_descriptor* d_out_desc);
 
 // stage-level helpers on plain (single-image, arbitrary pitch) buffers

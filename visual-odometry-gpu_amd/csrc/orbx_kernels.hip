@@ -843,39 +843,54 @@ __device__ __forceinline__ float harris_fast(const uint8_t* img, int w, int h, i
   constexpr int r = K / 2, P = K + 2;
   const int xs = x - r - 1;
   const int a0 = xs & ~3, off = xs - a0;
-  float p[P][P];
+  // all (K+2) x 3 dword loads first (one memory latency), then the window is
+  // consumed row by row with three rolling pixel rows / horizontal sums, which
+  // keeps the live set around 100 VGPRs instead of 160+
+  uint32_t raw[P][3];
 #pragma unroll
   for (int i = 0; i < P; i++) {
     const uint32_t* row = reinterpret_cast<const uint32_t*>(img + (size_t)(y - r - 1 + i) * pitch + a0);
-    const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];
-    const uint32_t q0 = __builtin_amdgcn_alignbyte(d1, d0, off), q1 = __builtin_amdgcn_alignbyte(d2, d1, off);
-    const uint32_t q2 = d2 >> (8 * off);
-    const uint32_t q[3] = {q0, q1, q2};
-#pragma unroll
-    for (int j = 0; j < P; j++) p[i][j] = (float)((q[j >> 2] >> (8 * (j & 3))) & 0xffu);
+    raw[i][0] = row[0];
+    raw[i][1] = row[1];
+    raw[i][2] = row[2];
   }
-  // vertical [1 2 1] (for gx) and horizontal [1 2 1] (for gy) partial sums
-  float vs[K][P], hs[P][K];
+  auto cvt_row = [&](int i, float (&out)[P]) {
+    const uint32_t q[3] = {__builtin_amdgcn_alignbyte(raw[i][1], raw[i][0], off),
+                           __builtin_amdgcn_alignbyte(raw[i][2], raw[i][1], off), raw[i][2] >> (8 * off)};
 #pragma unroll
-  for (int i = 0; i < K; i++)
+    for (int j = 0; j < P; j++) out[j] = (float)((q[j >> 2] >> (8 * (j & 3))) & 0xffu);
+  };
+  auto hsum = [&](const float (&pr)[P], float (&out)[K]) {
 #pragma unroll
-    for (int j = 0; j < P; j++) vs[i][j] = p[i][j] + 2.0f * p[i + 1][j] + p[i + 2][j];
-#pragma unroll
-  for (int i = 0; i < P; i++)
-#pragma unroll
-    for (int j = 0; j < K; j++) hs[i][j] = p[i][j] + 2.0f * p[i][j + 1] + p[i][j + 2];
+    for (int j = 0; j < K; j++) out[j] = pr[j] + 2.0f * pr[j + 1] + pr[j + 2];
+  };
+  float pr[3][P], hs[3][K];
+  cvt_row(0, pr[0]);
+  cvt_row(1, pr[1]);
+  hsum(pr[0], hs[0]);
+  hsum(pr[1], hs[1]);
   float a = 0.f, b = 0.f, c = 0.f;
 #pragma unroll
-  for (int i = 0; i < K; i++)
+  for (int i = 0; i < K; i++) {
+    // rows i, i+1, i+2 of the patch live in slots i%3, (i+1)%3, (i+2)%3
+    float(&p0)[P] = pr[i % 3];
+    float(&p1)[P] = pr[(i + 1) % 3];
+    float(&p2)[P] = pr[(i + 2) % 3];
+    cvt_row(i + 2, p2);
+    hsum(p2, hs[(i + 2) % 3]);
+    float vs[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) vs[j] = p0[j] + 2.0f * p1[j] + p2[j];
 #pragma unroll
     for (int j = 0; j < K; j++) {
-      const float gx = vs[i][j + 2] - vs[i][j];
-      const float gy = hs[i + 2][j] - hs[i][j];
+      const float gx = vs[j + 2] - vs[j];
+      const float gy = hs[(i + 2) % 3][j] - hs[i % 3][j];
       const float wgt = g[i * K + j];
       a = __fadd_rn(a, __fmul_rn(__fmul_rn(gx, gx), wgt));
       c = __fadd_rn(c, __fmul_rn(__fmul_rn(gy, gy), wgt));
       b = __fadd_rn(b, __fmul_rn(__fmul_rn(gx, gy), wgt));
     }
+  }
   const float det = __fsub_rn(__fmul_rn(a, c), __fmul_rn(b, b));
   const float trace = __fadd_rn(a, c);
   return __fsub_rn(det, __fmul_rn(__fmul_rn(kk, trace), trace));
@@ -1080,6 +1095,123 @@ __global__ __launch_bounds__(256) void k_harris_flat(const uint8_t* __restrict__
 //    counting (response desc, index asc) -- a deterministic total order -- and
 //    scatter the first `quota` to the frame's result slots.  Levels are laid
 //    out back to back in level order (src/orb.cpp:100-102).
+// ---------------------------------------------------------------------------
+// 4-6 fused: ordered compaction -> Harris -> top-N selection, one 512-thread
+// workgroup per (level, frame).  The three separate kernels were each bound by
+// launch + latency (512..2048 short workgroups, 10 + 35 + 22 us per batch); one
+// workgroup now carries its level's candidates from the survivor mask to the
+// selected list through LDS, with no intermediate global traffic and two
+// launches fewer.
+//   phase 1  row-major walk of the mask words (block scan of popcounts), first
+//            `cap` survivors -> LDS (src/orb_cpu.cpp:108-110 order and cap)
+//   phase 2  Harris response per candidate (thread per candidate, harris_any)
+//   phase 3  rank by the 64-bit (response desc, index asc) key, keep `quota`
+// The selected keypoints of level l go to the STATIC slots [out_off_l, out_off_l
+// + quota_l) of the frame (out_off_l = sum of the lower levels' quotas) plus a
+// per-level count; k_describe2 compacts them into the final order.
+#define LVL_THREADS 512
+__global__ __launch_bounds__(LVL_THREADS) void k_level_select(OrbxPlan plan, int mode, const u64* __restrict__ mask,
+                                                              const uint8_t* __restrict__ pyr,
+                                                              const float* __restrict__ gauss, int K, float kk,
+                                                              orbx_keypoint* __restrict__ sel_lkp,
+                                                              float* __restrict__ sel_resp,
+                                                              int32_t* __restrict__ sel_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+  __shared__ int s_wsum[LVL_THREADS / 64];
+  const int l = blockIdx.x, f = blockIdx.y;
+  const OrbxLevel& L = plan.L[l];
+  const int cap = L.cap, cap2 = (cap + 1) & ~1;
+  u64* s_key = reinterpret_cast<u64*>(s_dyn);                         // [cap2]
+  uint32_t* s_kp = reinterpret_cast<uint32_t*>(s_dyn + 8 * (size_t)cap2);  // [cap]  y << 16 | x
+  float* s_r = reinterpret_cast<float*>(s_dyn + 12 * (size_t)cap2);   // [cap]
+  const u64* m = mask + (size_t)f * plan.mask_words + L.mask_off;
+  const int nwords = L.h * L.mask_wpr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // phase 1: ordered compaction
+  int base = 0;
+  for (int w0 = 0; w0 < nwords && base < cap; w0 += LVL_THREADS) {
+    const int i = w0 + tid;
+    u64 v = i < nwords ? m[i] : 0ull;
+    const int c = __popcll(v);
+    const int incl = wave_scan_incl(c);
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < LVL_THREADS / 64; k++) {
+      const int sv = s_wsum[k];
+      if (k < wave) woff += sv;
+      tot += sv;
+    }
+    int pos = base + woff + incl - c;
+    if (c && pos < cap) {
+      const int y = i / L.mask_wpr, xw = i - y * L.mask_wpr;
+      while (v && pos < cap) {
+        const int b = __ffsll((long long)v) - 1;
+        v &= v - 1;
+        s_kp[pos++] = ((uint32_t)y << 16) | (uint32_t)(xw * 64 + b);
+      }
+    }
+    base += tot;
+    __syncthreads();
+  }
+  const int n = base < cap ? base : cap;
+  const int keep = n < L.quota ? n : L.quota;
+  const size_t so = (size_t)f * plan.out_cap + L.out_off;
+  if (tid == 0) sel_count[f * plan.nlevels + l] = keep;
+
+  if (mode == ORBX_SELECT_ROWMAJOR) {
+    for (int i = tid; i < keep; i += LVL_THREADS) {
+      const uint32_t p = s_kp[i];
+      orbx_keypoint kp;
+      kp.x = (int)(p & 0xffffu);
+      kp.y = (int)(p >> 16);
+      sel_lkp[so + i] = kp;
+      sel_resp[so + i] = 0.0f;
+    }
+    return;
+  }
+
+  // phase 2: Harris responses -> (response desc, index asc) keys
+  const uint8_t* img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
+  const int n2 = (n + 1) & ~1;
+  for (int i = tid; i < n2; i += LVL_THREADS) {
+    u64 key = 0ull;  // padding: the smallest key, never outranks anything
+    if (i < n) {
+      const uint32_t p = s_kp[i];
+      const float r = harris_any(img, L.w, L.h, L.pitch, (int)(p & 0xffffu), (int)(p >> 16), gauss, K, kk);
+      s_r[i] = r;
+      uint32_t u = orbx_f2u(r);
+      if (u == 0x80000000u) u = 0u;
+      u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+      key = ((u64)u << 32) | (uint32_t)~(uint32_t)i;
+    }
+    s_key[i] = key;
+  }
+  __syncthreads();
+
+  // phase 3: rank and scatter
+  for (int i = tid; i < n; i += LVL_THREADS) {
+    const u64 ki = s_key[i];
+    int rank = 0;
+#pragma unroll 4
+    for (int j = 0; j < n2; j += 2) {
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&s_key[j]);
+      rank += v.x > ki;
+      rank += v.y > ki;
+    }
+    if (rank < keep) {
+      const uint32_t p = s_kp[i];
+      orbx_keypoint kp;
+      kp.x = (int)(p & 0xffffu);
+      kp.y = (int)(p >> 16);
+      sel_lkp[so + rank] = kp;
+      sel_resp[so + rank] = s_r[i];
+    }
+  }
+}
+
 #define SELECT_SLICES 4  // workgroups per (level, frame): each ranks a quarter of the candidates
 __global__ __launch_bounds__(256) void k_select(OrbxPlan plan, int mode, const orbx_keypoint* __restrict__ cand,
                                                 const int32_t* __restrict__ cand_count,
@@ -1478,9 +1610,13 @@ __device__ __forceinline__ void desc_box_tables(DescLds& lds, int lane) {
 }
 
 __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t* __restrict__ pyr, int patch_size,
-                                                   const int32_t* __restrict__ out_count,
-                                                   const orbx_keypoint* __restrict__ out_lkp,
-                                                   const int32_t* __restrict__ out_level,
+                                                   const int32_t* __restrict__ sel_count,
+                                                   const orbx_keypoint* __restrict__ sel_lkp,
+                                                   const float* __restrict__ sel_resp,
+                                                   int32_t* __restrict__ out_count,
+                                                   orbx_keypoint* __restrict__ out_lkp,
+                                                   float* __restrict__ out_resp,
+                                                   int32_t* __restrict__ out_level,
                                                    orbx_keypoint* __restrict__ out_kp,
                                                    float* __restrict__ out_angle,
                                                    orbx_descriptor* __restrict__ out_desc) {
@@ -1489,7 +1625,16 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
   __shared__ float s_cs[DESC_KPB][2];
   const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int count = out_count[f];
+  // Final keypoint order = levels back to back (src/orb.cpp:100-102).  The selection
+  // kernel left level l's keypoints in static slots; the prefix sums of the per-level
+  // counts (one small load, wave-uniform arithmetic) map an output slot to them.
+  int pre[ORBX_MAX_LEVELS + 1];
+  pre[0] = 0;
+#pragma unroll
+  for (int i = 0; i < ORBX_MAX_LEVELS; i++)
+    pre[i + 1] = pre[i] + (i < plan.nlevels ? sel_count[f * plan.nlevels + i] : 0);
+  const int count = pre[ORBX_MAX_LEVELS];
+  if (blockIdx.x == 0 && tid == 0) out_count[f] = count;
   const int slot0 = blockIdx.x * DESC_KPB;
   if (slot0 >= count) return;  // whole workgroup
   DescLds& lds = s_lds[wave];
@@ -1506,9 +1651,19 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
 #pragma unroll
   for (int j = 0; j < DESC_KPW; j++) {
     const int slot = min(slot0 + wave * DESC_KPW + j, count - 1);
-    const int level = out_level[fo + slot];
-    jobs[j] = desc_job(plan, pyr, f, out_lkp[fo + slot], level);
+    int level = 0;
+#pragma unroll
+    for (int i = 1; i < ORBX_MAX_LEVELS; i++)
+      if (slot >= pre[i] && i < plan.nlevels) level = i;
+    const size_t src = fo + plan.L[level].out_off + (slot - pre[level]);
+    const orbx_keypoint kp = sel_lkp[src];
+    jobs[j] = desc_job(plan, pyr, f, kp, level);
     scale[j] = plan.L[level].scale;
+    if (j < nk && lane == 0) {  // the compacted per-keypoint records of the result block
+      out_lkp[fo + slot] = kp;
+      out_resp[fo + slot] = sel_resp[src];
+      out_level[fo + slot] = level;
+    }
   }
 #pragma unroll
   for (int j = 0; j < DESC_KPW; j++) desc_fetch_patch(jobs[j], lane, regs[j], offs[j]);
@@ -1884,14 +2039,28 @@ hipError_t orbx_launch_select(hipStream_t s, const OrbxPlan& plan, int n_frames,
   return ORBX_LAUNCH_CHECK();
 }
 
+hipError_t orbx_launch_level_select(hipStream_t s, const OrbxPlan& plan, int n_frames, int mode,
+                                    const unsigned long long* d_mask, const uint8_t* d_pyr, const float* d_gauss,
+                                    int window, float k, orbx_keypoint* d_sel_lkp, float* d_sel_resp,
+                                    int32_t* d_sel_count) {
+  int maxcap = 2;
+  for (int l = 0; l < plan.nlevels; l++) maxcap = plan.L[l].cap > maxcap ? plan.L[l].cap : maxcap;
+  const size_t lds = (size_t)((maxcap + 1) & ~1) * 16;
+  dim3 grid(plan.nlevels, n_frames);
+  hipLaunchKernelGGL(k_level_select, grid, dim3(LVL_THREADS), lds, s, plan, mode, d_mask, d_pyr, d_gauss, window, k,
+                     d_sel_lkp, d_sel_resp, d_sel_count);
+  return ORBX_LAUNCH_CHECK();
+}
+
 hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frames, const uint8_t* d_pyr,
-                                int patch_size, const int32_t* d_out_count, const orbx_keypoint* d_out_lkp,
-                                const int32_t* d_out_level, orbx_keypoint* d_out_kp, float* d_out_angle,
+                                int patch_size, const int32_t* d_sel_count, const orbx_keypoint* d_sel_lkp,
+                                const float* d_sel_resp, int32_t* d_out_count, orbx_keypoint* d_out_lkp,
+                                float* d_out_resp, int32_t* d_out_level, orbx_keypoint* d_out_kp, float* d_out_angle,
                                 orbx_descriptor* d_out_desc) {
   if (plan.out_cap <= 0) return hipSuccess;
   dim3 grid((plan.out_cap + DESC_KPB - 1) / DESC_KPB, n_frames);
-  hipLaunchKernelGGL(k_describe2, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_out_count, d_out_lkp,
-                     d_out_level, d_out_kp, d_out_angle, d_out_desc);
+  hipLaunchKernelGGL(k_describe2, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp, d_sel_resp,
+                     d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc);
   return ORBX_LAUNCH_CHECK();
 }
 
