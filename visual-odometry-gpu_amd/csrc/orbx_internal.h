@@ -126,13 +126,6 @@ hipError_t orbx_launch_compact(hipStream_t s, const OrbxPlan& plan, int n_frames
 hipError_t orbx_launch_harris_flat(hipStream_t s, const uint8_t* d_img, int w, int h, int pitch,
                                    const orbx_keypoint* d_kps, int nkp, const float* d_gauss, int K, float kk,
                                    float* d_resp);
-hipError_t orbx_launch_harris(hipStream_t s, const OrbxPlan& plan, int n_frames, const uint8_t* d_pyr,
-                              const orbx_keypoint* d_cand, const int32_t* d_cand_count, const float* d_gauss,
-                              int window, float k, float* d_resp);
-hipError_t orbx_launch_select(hipStream_t s, const OrbxPlan& plan, int n_frames, int mode,
-                              const orbx_keypoint* d_cand, const int32_t* d_cand_count, const float* d_resp,
-                              orbx_keypoint* d_out_lkp, float* d_out_resp, int32_t* d_out_level,
-                              int32_t* d_out_count);
 // fused compaction + Harris + selection, one workgroup per (level, frame)
 hipError_t orbx_launch_level_select(hipStream_t s, const OrbxPlan& plan, int n_frames, int mode,
                                     const unsigned long long* d_mask, const uint8_t* d_pyr, const float* d_gauss,

@@ -1024,30 +1024,6 @@ __device__ __forceinline__ float harris_group(const uint8_t* img, int w, int h, 
   return res;
 }
 
-// G lanes per keypoint: G = 8 -> one window row per lane, G = 4 -> two rows per lane
-template <int G>
-__global__ __launch_bounds__(256) void k_harris2(OrbxPlan plan, const uint8_t* __restrict__ pyr,
-                                                 const orbx_keypoint* __restrict__ cand,
-                                                 const int32_t* __restrict__ cand_count,
-                                                 const float* __restrict__ gauss, int K, float kk,
-                                                 float* __restrict__ resp) {
-  constexpr int RPL = G == 8 ? 1 : 2;
-  const int j = blockIdx.x * (256 / G) + threadIdx.x / G, sub = threadIdx.x & (G - 1);
-  const int f = blockIdx.y;
-  int l = 0;
-  for (int i = 1; i < plan.nlevels; i++)
-    if (j >= plan.L[i].cand_off) l = i;
-  const OrbxLevel& L = plan.L[l];
-  const bool active = j < plan.cand_total && (j - L.cand_off) < cand_count[f * plan.nlevels + l];
-  orbx_keypoint kp = {4, 4};
-  if (active) kp = cand[(size_t)f * plan.cand_total + j];
-  // lanes of one wave may sit on different levels: the level image is per lane
-  const uint8_t* img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
-  bool writer;
-  const float v = harris_group<RPL, G>(img, L.w, L.h, L.pitch, kp.x, kp.y, gauss, K, kk, sub, active, writer);
-  if (writer) resp[(size_t)f * plan.cand_total + j] = v;
-}
-
 __global__ __launch_bounds__(256) void k_harris2_flat(const uint8_t* __restrict__ img, int w, int h, int pitch,
                                                       const orbx_keypoint* __restrict__ kps, int nkp,
                                                       const float* __restrict__ gauss, int K, float kk,
@@ -1062,33 +1038,6 @@ __global__ __launch_bounds__(256) void k_harris2_flat(const uint8_t* __restrict_
   if (writer) resp[j] = v;
 }
 
-__global__ __launch_bounds__(256) void k_harris(OrbxPlan plan, const uint8_t* __restrict__ pyr,
-                                                const orbx_keypoint* __restrict__ cand,
-                                                const int32_t* __restrict__ cand_count,
-                                                const float* __restrict__ gauss, int K, float kk,
-                                                float* __restrict__ resp) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  const int f = blockIdx.y;
-  if (j >= plan.cand_total) return;
-  int l = 0;
-  for (int i = 1; i < plan.nlevels; i++)
-    if (j >= plan.L[i].cand_off) l = i;
-  const OrbxLevel& L = plan.L[l];
-  const int idx = j - L.cand_off;
-  if (idx >= cand_count[f * plan.nlevels + l]) return;
-  const orbx_keypoint kp = cand[(size_t)f * plan.cand_total + j];
-  const uint8_t* img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
-  resp[(size_t)f * plan.cand_total + j] = harris_any(img, L.w, L.h, L.pitch, kp.x, kp.y, gauss, K, kk);
-}
-
-__global__ __launch_bounds__(256) void k_harris_flat(const uint8_t* __restrict__ img, int w, int h, int pitch,
-                                                     const orbx_keypoint* __restrict__ kps, int nkp,
-                                                     const float* __restrict__ gauss, int K, float kk,
-                                                     float* __restrict__ resp) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= nkp) return;
-  resp[j] = harris_any(img, w, h, pitch, kps[j].x, kps[j].y, gauss, K, kk);
-}
 
 // ---------------------------------------------------------------------------
 // 6. per-level selection (src/orb.cpp:67-86 intent): rank every candidate by
@@ -1210,84 +1159,6 @@ __global__ __launch_bounds__(LVL_THREADS) void k_level_select(OrbxPlan plan, int
       sel_resp[so + rank] = s_r[i];
     }
   }
-}
-
-#define SELECT_SLICES 4  // workgroups per (level, frame): each ranks a quarter of the candidates
-__global__ __launch_bounds__(256) void k_select(OrbxPlan plan, int mode, const orbx_keypoint* __restrict__ cand,
-                                                const int32_t* __restrict__ cand_count,
-                                                const float* __restrict__ resp,
-                                                orbx_keypoint* __restrict__ out_lkp,
-                                                float* __restrict__ out_resp, int32_t* __restrict__ out_level,
-                                                int32_t* __restrict__ out_count) {
-  extern __shared__ __attribute__((aligned(16))) float s_r[];  // max per-level cap, rounded up to 4
-  const int l = blockIdx.x / SELECT_SLICES, slice = blockIdx.x - l * SELECT_SLICES;
-  const int f = blockIdx.y, tid = threadIdx.x;
-  const int abl = mode >> 4;  // timing diagnostics only
-  mode &= 15;
-  if (abl & 8) return;
-  const OrbxLevel& L = plan.L[l];
-  // all level counts with ONE memory round trip (lanes 0..nlevels-1), then the
-  // output offset of this level = sum of the kept counts of the levels below
-  __shared__ int s_cnt[ORBX_MAX_LEVELS];
-  if (tid < plan.nlevels) s_cnt[tid] = cand_count[f * plan.nlevels + tid];
-  __syncthreads();
-  const int n = s_cnt[l];
-  const int keep = n < L.quota ? n : L.quota;
-  int out_off = 0;
-  if (!(abl & 2))
-  for (int i = 0; i < l; i++) {
-    const int c = s_cnt[i];
-    out_off += c < plan.L[i].quota ? c : plan.L[i].quota;
-  }
-  if (abl & 4) return;
-  const orbx_keypoint* ck = cand + (size_t)f * plan.cand_total + L.cand_off;
-  const float* cr = resp + (size_t)f * plan.cand_total + L.cand_off;
-  orbx_keypoint* ok = out_lkp + (size_t)f * plan.out_cap + out_off;
-  float* orr = out_resp + (size_t)f * plan.out_cap + out_off;
-  int32_t* ol = out_level + (size_t)f * plan.out_cap + out_off;
-  if (mode == ORBX_SELECT_ROWMAJOR) {
-    for (int i = slice * 256 + tid; i < keep; i += 256 * SELECT_SLICES) {
-      ok[i] = ck[i];
-      orr[i] = 0.0f;
-      ol[i] = l;
-    }
-  } else {
-    // Total order (response desc, index asc) as ONE unsigned 64-bit key per
-    // candidate: high word = order-preserving image of the float (-0 folded into
-    // +0 so that equal floats give equal words), low word = ~index.  Ranking is
-    // then one 64-bit compare + one add-with-carry per pair instead of three
-    // compares and two mask ops.
-    u64* s_key = reinterpret_cast<u64*>(s_r);
-    const int n2 = (n + 1) & ~1;
-    for (int i = tid; i < n2; i += 256) {
-      u64 k = 0ull;  // padding: the smallest key, never outranks anything
-      if (i < n) {
-        uint32_t u = orbx_f2u(cr[i]);
-        if (u == 0x80000000u) u = 0u;
-        u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
-        k = ((u64)u << 32) | (uint32_t)~(uint32_t)i;
-      }
-      s_key[i] = k;
-    }
-    __syncthreads();
-    for (int i = slice * 256 + tid; i < n; i += 256 * SELECT_SLICES) {
-      const u64 ki = s_key[i];
-      const float ri = cr[i];
-      int rank = 0;
-#pragma unroll 4
-      for (int j = 0; j < ((abl & 1) ? 0 : n2); j += 2) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&s_key[j]);
-        rank += v.x > ki;
-        rank += v.y > ki;
-      }
-      if (rank < keep) {
-        ok[rank] = ck[i];
-        orr[rank] = ri;
-        ol[rank] = l;
-      }
-    }
-  }
-  if (l == plan.nlevels - 1 && slice == 0 && tid == 0) out_count[f] = out_off + keep;
 }
 
 __global__ __launch_bounds__(256) void k_select_flat(const float* __restrict__ resp, int n, int keep,
@@ -1993,49 +1864,6 @@ hipError_t orbx_launch_compact(hipStream_t s, const OrbxPlan& plan, int n_frames
   dim3 grid(plan.nlevels, n_frames);
   hipLaunchKernelGGL(k_compact, grid, dim3(256), 0, s, plan, d_mask, d_cand, d_cand_count, d_cand_total,
                      need_total);
-  return ORBX_LAUNCH_CHECK();
-}
-
-hipError_t orbx_launch_harris(hipStream_t s, const OrbxPlan& plan, int n_frames, const uint8_t* d_pyr,
-                              const orbx_keypoint* d_cand, const int32_t* d_cand_count, const float* d_gauss,
-                              int window, float k, float* d_resp) {
-  if (plan.cand_total <= 0) return hipSuccess;
-  static const int impl = [] {
-    const char* e = getenv("ORBX_HARRIS_IMPL");  // 1 = thread-per-keypoint kernel (A/B timing)
-    return e ? atoi(e) : 2;  // 3 = always the 8-lane kernel
-  }();
-  // thread-per-keypoint does less total work and wins once there are enough keypoints
-  // to fill the chip (34 vs 44 us at 64 frames); the 8-lane kernel has the shorter
-  // critical path and wins for a few frames (22 vs 27 us at one frame)
-  const bool many = (long long)plan.cand_total * n_frames >= 16384;
-  if (impl == 1 || (impl == 2 && many)) {
-    dim3 grid((plan.cand_total + 255) / 256, n_frames);
-    hipLaunchKernelGGL(k_harris, grid, dim3(256), 0, s, plan, d_pyr, d_cand, d_cand_count, d_gauss, window, k,
-                       d_resp);
-  } else if (impl == 4) {  // two window rows per lane: measured slower than both (47 us), kept for A/B
-    dim3 grid((plan.cand_total + 63) / 64, n_frames);
-    hipLaunchKernelGGL(k_harris2<4>, grid, dim3(256), 0, s, plan, d_pyr, d_cand, d_cand_count, d_gauss, window, k,
-                       d_resp);
-  } else {
-    dim3 grid((plan.cand_total + 31) / 32, n_frames);
-    hipLaunchKernelGGL(k_harris2<8>, grid, dim3(256), 0, s, plan, d_pyr, d_cand, d_cand_count, d_gauss, window, k,
-                       d_resp);
-  }
-  return ORBX_LAUNCH_CHECK();
-}
-
-hipError_t orbx_launch_select(hipStream_t s, const OrbxPlan& plan, int n_frames, int mode,
-                              const orbx_keypoint* d_cand, const int32_t* d_cand_count, const float* d_resp,
-                              orbx_keypoint* d_out_lkp, float* d_out_resp, int32_t* d_out_level,
-                              int32_t* d_out_count) {
-  dim3 grid(plan.nlevels * SELECT_SLICES, n_frames);
-  int maxcap = 4;
-  for (int l = 0; l < plan.nlevels; l++) maxcap = plan.L[l].cap > maxcap ? plan.L[l].cap : maxcap;
-  const size_t lds = (size_t)((maxcap + 3) & ~3) * sizeof(unsigned long long);
-  static const int abl = [] { const char* e = getenv("ORBX_SELECT_ABLATE"); return e ? atoi(e) : 0; }();
-  mode |= abl << 4;
-  hipLaunchKernelGGL(k_select, grid, dim3(256), lds, s, plan, mode, d_cand, d_cand_count, d_resp, d_out_lkp,
-                     d_out_resp, d_out_level, d_out_count);
   return ORBX_LAUNCH_CHECK();
 }
 
