@@ -1,15 +1,19 @@
 // orbx_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the ORB front-end.
 //
-// Design notes (see DESIGN.md for the full picture):
-//  * 64-lane wavefronts everywhere: 256-thread workgroups = 4 waves; wave
-//    ballots (64-bit) do the FAST candidate compaction, the NMS survivor
-//    bit-mask (one 64-pixel tile row == one ballot == one u64 store) and the
-//    BRIEF bit packing (4 ballots == one 256-bit descriptor).
-//  * Every image read is a row-coalesced, 4-byte-aligned dword load into an
-//    LDS tile that includes the halo; all 8-bit stencil work then runs out of
-//    LDS.  No MFMA: this path is integer stencil / gather, HBM-bound.
-//  * All levels of all frames of a batch are covered by ONE launch per stage
-//    (blockIdx.x -> (level, tile) through OrbxTileMap, blockIdx.y -> frame).
+// Design notes (see DESIGN.md §6 for the full picture and the measurements):
+//  * 64-lane wavefronts everywhere.  Cross-lane work uses DPP (wave_shr/shl for
+//    the blur's left/right neighbours, row scans and reductions, the Harris sum
+//    hand-off) and 64-bit ballots (4 ballots == one 256-bit BRIEF descriptor).
+//  * Pixels are processed 4 per lane as aligned dwords; the 8-bit stencil math
+//    runs on packed 16-bit lanes (v_perm_b32 + v_pk_*_u16).  No MFMA: nothing
+//    here is a dense contraction.  Every kernel turned out to be bound by VALU
+//    issue (one wave64 instruction per SIMD per 4 clocks), so the designs
+//    minimise instructions per pixel first, memory traffic second.
+//  * Row-coalesced aligned loads: straight into registers where a stencil can
+//    stream (blur, pyramid), into an LDS tile with halo where it needs random
+//    access (FAST ring gathers, BRIEF patches).
+//  * All levels of all frames of a batch are covered by ONE launch per stage;
+//    each workgroup reads its tile from a 64-byte OrbxTileDesc record.
 //  * Keypoint order is deterministic (row-major), never atomics-ordered.
 //  * Integer arithmetic wherever the reference's float arithmetic is exact, so
 //    results are bit-identical to the CPU oracle; the float parts (angles,
@@ -740,7 +744,8 @@ __global__ __launch_bounds__(256) void k_fast_nms2(const OrbxTileDesc* __restric
 }
 
 // ---------------------------------------------------------------------------
-// 4. ordered compaction of the survivor mask: one workgroup per (level,
+// 4. (stage operators Fast()/NMS() only; the whole path uses the fused kernel below)
+//    ordered compaction of the survivor mask: one workgroup per (level,
 //    frame) walks the mask words in row-major order, a block-wide exclusive
 //    scan of popcounts gives every set bit its row-major rank, the first
 //    `cap` are written (src/orb_cpu.cpp:108-110 order and cap -- NOT the
@@ -1040,11 +1045,6 @@ __global__ __launch_bounds__(256) void k_harris2_flat(const uint8_t* __restrict_
 
 
 // ---------------------------------------------------------------------------
-// 6. per-level selection (src/orb.cpp:67-86 intent): rank every candidate by
-//    counting (response desc, index asc) -- a deterministic total order -- and
-//    scatter the first `quota` to the frame's result slots.  Levels are laid
-//    out back to back in level order (src/orb.cpp:100-102).
-// ---------------------------------------------------------------------------
 // 4-6 fused: ordered compaction -> Harris -> top-N selection, one 512-thread
 // workgroup per (level, frame).  The three separate kernels were each bound by
 // launch + latency (512..2048 short workgroups, 10 + 35 + 22 us per batch); one
@@ -1176,7 +1176,8 @@ __global__ __launch_bounds__(256) void k_select_flat(const float* __restrict__ r
 }
 
 // ---------------------------------------------------------------------------
-// 7. orientation + rotated BRIEF-256, one wavefront per keypoint
+// 7. (stage operators Orientations()/Brief() only; the whole path uses 7b)
+//    orientation + rotated BRIEF-256, one wavefront per keypoint
 //    (src/orb_cpu.cpp:139-258; src/cuda/Orientations.cu:22-63,
 //    src/cuda/Brief.cu:40-95).
 //    The 41x41 neighbourhood (pattern radius 18 + 5x5 box radius 2, and the
