@@ -388,3 +388,17 @@ def test_fast_candidate_queue_overflow(ctx):
         kr, tot = O.nms(s, 3, 100000)
         kg, gtot = ctx.fast(img, t, 9, 3, 100000)
         assert gtot == tot and np.array_equal(kg, kr)
+
+
+@pytest.mark.parametrize("select_mode", [0, 1])
+def test_zero_feature_budget(pkg, select_mode):
+    """nfeatures too small for any per-level quota (orb.cpp:62 truncates to 0): count must be 0, not stale memory
+    (regression: the describe launch that writes the counts is skipped when the output capacity is 0)."""
+    img = synth(3, 131, 55, "noise")
+    p = pkg.default_params("gpu", max_width=55, max_height=131, max_batch=4, nfeatures=0, nlevels=2)
+    p.select_mode = select_mode
+    with pkg.Context(p) as c:
+        c.batch_host(np.stack([img] * 4))
+        r = c.batch_fetch(0, 4, 1)
+        assert np.array_equal(r["counts"], np.zeros(4, np.int32))
+        assert c.detect_and_compute(img)["count"] == 0

@@ -558,6 +558,8 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   HIPCHK(c, orbx_launch_level_select(s, P, n, c->p.select_mode, c->d_mask, final_pyr(c), c->d_gauss,
                                      c->p.harris_window, c->p.harris_k, c->d_cand, c->d_resp, c->d_cand_count));
   HIPCHK(c, mark(6, false));
+  if (P.out_cap <= 0)  // nfeatures too small for any quota: no describe launch, so the counts are zeroed here
+    HIPCHK(c, hipMemsetAsync(c->d_out + o.counts, 0, sizeof(int32_t) * (size_t)n, s));
   HIPCHK(c, orbx_launch_describe(s, P, n, final_pyr(c), c->p.patch_size, c->d_cand_count, c->d_cand, c->d_resp,
                                  (int32_t*)(c->d_out + o.counts), (orbx_keypoint*)(c->d_out + o.lkp),
                                  (float*)(c->d_out + o.resp), (int32_t*)(c->d_out + o.level),
