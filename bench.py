@@ -181,6 +181,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dt = grp.max_float(dt)
+    fast_tiles = ctx.fast_tile_counts()  # (did the full work, all) of the last timed step
     if not args.no_stage_events:
         nread = min(args.steps, 64)
         for back in range(nread):
@@ -295,6 +296,8 @@ def main():
                          "blur_plus_fast": {"achieved": both, "frac": both / HBM_PEAK_GBS,
                                             "algorithmic_bytes_per_step": alg["blur"] + alg["fast_nms"]}},
             "roofline_kernels_ms": roof_ms,
+            "fast_tiles": {"full_work": fast_tiles[0], "total": fast_tiles[1],
+                           "early_exit_frac": 1.0 - fast_tiles[0] / max(fast_tiles[1], 1)},
             "stage_ms_per_step": stage_ms,
             "fps_with_d2h": world * B / dt_d2h,
             "single_frame_host_to_host": single,

@@ -169,6 +169,11 @@ int orbx_stage_times_history(orbx_ctx* ctx, int back, float* ms);
  * to measure the kernel's full-work throughput).  Default: enabled. */
 int orbx_set_fast_early_exit(orbx_ctx* ctx, int enable);
 
+/* Diagnostics of the last whole-path batch: how many FAST/NMS tiles did the full
+ * work (`worked`) out of all tiles of the batch (`total`); the rest took the early
+ * exit.  With the early exit disabled worked == total. */
+int orbx_fast_tile_counts(orbx_ctx* ctx, long long* worked, long long* total);
+
 /* Runs only the blur + FAST/NMS stages of the last-built pyramid `reps` times
  * (the roofline kernels) and reports the average duration of
  * each, measured with HIP events on the context's stream. */

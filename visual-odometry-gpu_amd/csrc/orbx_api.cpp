@@ -71,9 +71,9 @@ struct orbx_ctx {
   OrbxBandMap bm_fast{};
   unsigned long long* d_row_stat = nullptr;
   // per-workgroup tile descriptor tables (see OrbxTileDesc)
-  OrbxTileDesc* d_tiles_fast = nullptr;  // band-major, built for fast_tiles_n frames
+  OrbxTileDesc* d_tiles_fast = nullptr;  // one frame, band-major
   size_t tiles_fast_capacity = 0;
-  int fast_tiles_n = 0, fast_tiles_count = 0;
+  int fast_tiles_count = 0;
   OrbxTileDesc* d_tiles_blur2 = nullptr;
   OrbxTileDesc* d_tiles_pyr2 = nullptr;
   size_t tiles_frame_capacity = 0;
@@ -212,34 +212,34 @@ int make_bandmap(const OrbxPlan& plan, OrbxBandMap* bm, std::string* why) {
   return ORBX_OK;
 }
 
-// FAST tiles of n frames in band-major order (levels shrink with the level index,
-// so the levels that have a tile row b are always a prefix of the level list)
-void build_fast_tiles(const OrbxPlan& plan, const OrbxBandMap& bm, int n, std::vector<OrbxTileDesc>* out) {
+// FAST tiles of ONE frame in band-major order (the kernel's grid is frames x tiles with
+// the frame index dispatched fastest, so tile row b of every frame runs before tile row
+// b+1 of any frame).  Tile rows >= first_band only; a workgroup owns `strip` tiles of a row.
+void build_fast_tiles(const OrbxPlan& plan, const OrbxBandMap& bm, int first_band, int strip,
+                      std::vector<OrbxTileDesc>* out) {
   out->clear();
-  out->reserve((size_t)bm.band_begin[bm.nbands] * n);
-  for (int b = 0; b < bm.nbands; b++)
-    for (int f = 0; f < n; f++)
-      for (int l = 0; l < plan.nlevels; l++) {
-        if (bm.tiles_y[l] <= b) continue;
-        const OrbxLevel& L = plan.L[l];
-        for (int tx = 0; tx < bm.tiles_x[l]; tx++) {
-          OrbxTileDesc d{};
-          d.l = l;
-          d.tx = tx;
-          d.ty = b;
-          d.f = f;
-          d.w = L.w;
-          d.h = L.h;
-          d.pitch = L.pitch;
-          d.u0 = L.cap;
-          d.u1 = L.mask_wpr;
-          d.u2 = bm.tiles_x[l];
-          d.stat_index = (uint32_t)(((size_t)f * ORBX_MAX_LEVELS + l) * ORBX_MAX_BANDS);
-          d.img_off = (uint64_t)f * plan.frame_bytes + L.img_off;
-          d.mask_off = (uint64_t)f * plan.mask_words + L.mask_off;
-          out->push_back(d);
-        }
+  for (int b = first_band; b < bm.nbands; b++)
+    for (int l = 0; l < plan.nlevels; l++) {
+      if (bm.tiles_y[l] <= b) continue;
+      const OrbxLevel& L = plan.L[l];
+      for (int tx = 0; tx < bm.tiles_x[l]; tx += strip) {
+        OrbxTileDesc d{};
+        d.l = l;
+        d.tx = tx;
+        d.ty = b;
+        d.f = std::min(strip, bm.tiles_x[l] - tx);  // tiles in this workgroup's strip
+        d.w = L.w;
+        d.h = L.h;
+        d.pitch = L.pitch;
+        d.u0 = L.cap;
+        d.u1 = L.mask_wpr;
+        d.u2 = bm.tiles_x[l];
+        d.stat_index = (uint32_t)(l * ORBX_MAX_BANDS);
+        d.img_off = (uint64_t)L.img_off;
+        d.mask_off = (uint64_t)L.mask_off;
+        out->push_back(d);
       }
+    }
 }
 
 // tiles of ONE frame, level-major, for the blur / pyramid kernels (blockIdx.y = frame)
@@ -447,23 +447,16 @@ int set_plan(orbx_ctx* c, int w, int h) {
     HIPCHK(c, hipMemcpy(c->d_tiles_pyr2, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
     c->pyr2_tiles_count = (int)t.size();
   }
-  c->fast_tiles_n = 0;  // the FAST table depends on the plan and on the batch size
+  {
+    std::vector<OrbxTileDesc> t;
+    build_fast_tiles(plan, c->bm_fast, 0, 1, &t);
+    if (t.size() > c->tiles_fast_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "FAST tile table exceeds pool");
+    c->fast_tiles_count = (int)t.size();
+    if (!t.empty())
+      HIPCHK(c, hipMemcpy(c->d_tiles_fast, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
+  }
   c->plan_w = w;
   c->plan_h = h;
-  return ORBX_OK;
-}
-
-// FAST tile table for n frames of the current plan (rebuilt only when n or the plan changes)
-int ensure_fast_tiles(orbx_ctx* c, int n) {
-  if (c->fast_tiles_n == n) return ORBX_OK;
-  std::vector<OrbxTileDesc> t;
-  build_fast_tiles(c->plan, c->bm_fast, n, &t);
-  if (t.size() > c->tiles_fast_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "FAST tile table exceeds pool");
-  // an in-flight batch may still be reading the previous table
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(c->d_tiles_fast, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
-  c->fast_tiles_n = n;
-  c->fast_tiles_count = (int)t.size();
   return ORBX_OK;
 }
 
@@ -488,17 +481,19 @@ const uint8_t* final_pyr(const orbx_ctx* c);
 // first `cap` row-major survivors exit early (see decode_band in the kernels);
 // ORBX_FAST_EARLY=0 disables that (every tile does the full work).
 hipError_t launch_fast_whole(orbx_ctx* c, hipStream_t s, int n, OrbxFastParams fp, bool stats_zeroed = false) {
-  if (c->fast_tiles_n != n) return hipErrorInvalidValue;  // ensure_fast_tiles() must have run
   static const int early_env = [] {
     const char* e = getenv("ORBX_FAST_EARLY");
     return e ? atoi(e) : 1;
   }();
   unsigned long long* stat = (early_env && c->fast_early) ? c->d_row_stat : nullptr;
   if (stat && !stats_zeroed) {
-    hipError_t e = hipMemsetAsync(stat, 0, (size_t)n * ORBX_MAX_LEVELS * ORBX_MAX_BANDS * 8, s);
+    hipError_t e = hipMemsetAsync(stat, 0, (size_t)n * ORBX_FAST_STAT_WORDS * 8, s);
     if (e != hipSuccess) return e;
   }
-  return orbx_launch_fast_nms(s, c->d_tiles_fast, c->fast_tiles_count, final_pyr(c), fp, c->d_mask, nullptr, stat);
+  // (a two-launch variant -- tile row 0 first, the rest in strips of several tiles per
+  // workgroup -- was measured slower: the kernel boundary costs more than the cheaper exits save)
+  return orbx_launch_fast_nms(s, c->d_tiles_fast, c->fast_tiles_count, n, final_pyr(c), c->plan.frame_bytes,
+                              c->plan.mask_words, fp, c->d_mask, nullptr, stat);
 }
 
 // separable kind -> register-streaming kernel; /273 kind -> LDS tile kernel.
@@ -538,7 +533,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   };
   // tile-row statistics of the FAST early exit: zeroed up front so that the events
   // around the FAST stage bracket the kernel alone
-  HIPCHK(c, hipMemsetAsync(c->d_row_stat, 0, (size_t)n * ORBX_MAX_LEVELS * ORBX_MAX_BANDS * 8, s));
+  HIPCHK(c, hipMemsetAsync(c->d_row_stat, 0, (size_t)n * ORBX_FAST_STAT_WORDS * 8, s));
   HIPCHK(c, mark(0, false));
   HIPCHK(c, launch_pyramid_auto(c, s, n, d_frames, row_stride, frame_stride));
   HIPCHK(c, mark(1, true));
@@ -547,7 +542,6 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
                                c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
   HIPCHK(c, mark(2, true));
   OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2, fast_ablate()};
-  if ((st = ensure_fast_tiles(c, n)) != ORBX_OK) return st;
   HIPCHK(c, launch_fast_whole(c, s, n, fp, true));
   HIPCHK(c, mark(3, true));
   HIPCHK(c, mark(4, false));  // (compaction, Harris and selection are one kernel: its time is the "select" slot)
@@ -757,14 +751,14 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
   if (p->blur_levels != ORBX_BLUR_NONE)
     CREATE_CHK(hipMalloc((void**)&c->d_pyr_blur, B * (size_t)M.frame_bytes + 256));
   CREATE_CHK(hipMalloc((void**)&c->d_mask, B * (size_t)M.mask_words * 8 + 256));
-  CREATE_CHK(hipMalloc((void**)&c->d_row_stat, B * ORBX_MAX_LEVELS * ORBX_MAX_BANDS * 8));
+  CREATE_CHK(hipMalloc((void**)&c->d_row_stat, B * ORBX_FAST_STAT_WORDS * 8));
   {
     OrbxBandMap bmm;
     if ((st = make_bandmap(M, &bmm, &why)) != ORBX_OK) {
       orbx_destroy(c);
       return fail(nullptr, st, why);
     }
-    c->tiles_fast_capacity = (size_t)bmm.band_begin[bmm.nbands] * B;
+    c->tiles_fast_capacity = (size_t)bmm.band_begin[bmm.nbands];
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_fast, std::max<size_t>(c->tiles_fast_capacity, 1) * sizeof(OrbxTileDesc)));
     std::vector<OrbxTileDesc> t1, t2;
     build_frame_tiles(M, ORBX_BLUR2_TW, 4 * 16, false, &t1);  // the smaller strip height gives the larger table
@@ -860,6 +854,23 @@ int orbx_wait(orbx_ctx* c) {
 int orbx_set_fast_early_exit(orbx_ctx* c, int enable) {
   if (!c) return ORBX_ERR_INVALID_ARG;
   c->fast_early = enable != 0;
+  return ORBX_OK;
+}
+
+int orbx_fast_tile_counts(orbx_ctx* c, long long* worked, long long* total) {
+  if (!c || !worked || !total) return ORBX_ERR_INVALID_ARG;
+  if (c->plan_w == 0 || c->last_n < 1) return fail(c, ORBX_ERR_INVALID_ARG, "run a batch first");
+  const int n = c->last_n;
+  std::vector<unsigned long long> h((size_t)n * ORBX_FAST_STAT_WORDS);
+  HIPCHK(c, hipStreamSynchronize(c->last_stream));
+  HIPCHK(c, hipMemcpy(h.data(), c->d_row_stat, h.size() * 8, hipMemcpyDeviceToHost));
+  long long w = 0;
+  for (int f = 0; f < n; f++)
+    for (int l = 0; l < c->plan.nlevels; l++)
+      for (int b = 0; b < c->bm_fast.tiles_y[l]; b++)
+        w += (long long)(h[(size_t)f * ORBX_FAST_STAT_WORDS + (size_t)l * ORBX_MAX_BANDS + b] >> 32);
+  *worked = w;
+  *total = (long long)c->bm_fast.band_begin[c->bm_fast.nbands] * n;
   return ORBX_OK;
 }
 
@@ -973,10 +984,6 @@ int orbx_bench_stage(orbx_ctx* c, int n_frames, int stage, int reps, float* avg_
                                    c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
         break;
       case ORBX_STAGE_FAST:
-        {
-          int st2 = ensure_fast_tiles(c, n_frames);
-          if (st2 != ORBX_OK) return st2;
-        }
         HIPCHK(c, launch_fast_whole(c, s, n_frames, fp));
         break;
       case ORBX_STAGE_COMPACT:
@@ -1010,7 +1017,7 @@ int orbx_fast_score(orbx_ctx* c, const uint8_t* image, int width, int height, in
   std::string why;
   if ((st = make_bandmap(P, &bm, &why)) != ORBX_OK) return fail(c, st, why);
   std::vector<OrbxTileDesc> t;
-  build_fast_tiles(P, bm, 1, &t);
+  build_fast_tiles(P, bm, 0, 1, &t);
   if ((st = ensure(c, c->s_tiles, t.size() * sizeof(OrbxTileDesc))) != ORBX_OK) return st;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->s_tiles.p, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
@@ -1018,9 +1025,9 @@ int orbx_fast_score(orbx_ctx* c, const uint8_t* image, int width, int height, in
   if ((st = ensure(c, c->s_u16, npx * 2)) != ORBX_OK) return st;
   if ((st = ensure(c, c->s_mask, (size_t)P.mask_words * 8)) != ORBX_OK) return st;
   OrbxFastParams fp{threshold, n, 0, 0};
-  HIPCHK(c, orbx_launch_fast_nms(c->stream, (const OrbxTileDesc*)c->s_tiles.p, (int)t.size(),
-                                 (const uint8_t*)c->s_img_a.p, fp, (unsigned long long*)c->s_mask.p,
-                                 (uint16_t*)c->s_u16.p, nullptr));
+  HIPCHK(c, orbx_launch_fast_nms(c->stream, (const OrbxTileDesc*)c->s_tiles.p, (int)t.size(), 1,
+                                 (const uint8_t*)c->s_img_a.p, P.frame_bytes, P.mask_words, fp,
+                                 (unsigned long long*)c->s_mask.p, (uint16_t*)c->s_u16.p, nullptr));
   std::vector<uint16_t> h(npx);
   HIPCHK(c, hipMemcpyAsync(h.data(), c->s_u16.p, npx * 2, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1061,15 +1068,16 @@ int orbx_fast(orbx_ctx* c, const uint8_t* image, int width, int height, int stri
   std::string why;
   if ((st = make_bandmap(P, &bm, &why)) != ORBX_OK) return fail(c, st, why);
   std::vector<OrbxTileDesc> t;
-  build_fast_tiles(P, bm, 1, &t);
+  build_fast_tiles(P, bm, 0, 1, &t);
   if ((st = ensure(c, c->s_tiles, t.size() * sizeof(OrbxTileDesc))) != ORBX_OK) return st;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->s_tiles.p, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
   if ((st = ensure(c, c->s_mask, (size_t)P.mask_words * 8)) != ORBX_OK) return st;
   OrbxFastParams fp{threshold, n, nms_window / 2, 0};
   // stage operator: exact totals are part of the contract -> no early exit
-  HIPCHK(c, orbx_launch_fast_nms(c->stream, (const OrbxTileDesc*)c->s_tiles.p, (int)t.size(),
-                                 (const uint8_t*)c->s_img_a.p, fp, (unsigned long long*)c->s_mask.p, nullptr, nullptr));
+  HIPCHK(c, orbx_launch_fast_nms(c->stream, (const OrbxTileDesc*)c->s_tiles.p, (int)t.size(), 1,
+                                 (const uint8_t*)c->s_img_a.p, P.frame_bytes, P.mask_words, fp,
+                                 (unsigned long long*)c->s_mask.p, nullptr, nullptr));
   return compact_and_fetch(c, P, nfeatures, keypoints, count, total);
 }
 

@@ -48,6 +48,9 @@ struct OrbxTileMap {
 
 // band-major workgroup order of the FAST kernel (see decode_band)
 #define ORBX_MAX_BANDS 64
+// FAST early-exit state per frame (u64 words): tile-row statistics [level][band], then one
+// "dead from band" word per level
+#define ORBX_FAST_STAT_WORDS (ORBX_MAX_LEVELS * ORBX_MAX_BANDS + ORBX_MAX_LEVELS)
 struct OrbxBandMap {
   int32_t nbands;
   int32_t band_begin[ORBX_MAX_BANDS + 1];  // tiles PER FRAME before band b (+ total)
@@ -117,8 +120,9 @@ hipError_t orbx_launch_blur(hipStream_t s, const OrbxPlan& plan, const OrbxTileM
 hipError_t orbx_launch_blur2(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int n_frames,
                              const uint8_t* d_src, uint8_t* d_dst, int first_level);
 // d_tiles: n_tiles OrbxTileDesc in band-major order (orbx_api.cpp: build_fast_tiles)
-hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, const uint8_t* d_pyr,
-                                OrbxFastParams fp, unsigned long long* d_mask, uint16_t* d_scores_dbg,
+hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int n_frames,
+                                const uint8_t* d_pyr, int frame_bytes, int mask_words, OrbxFastParams fp,
+                                unsigned long long* d_mask, uint16_t* d_scores_dbg,
                                 unsigned long long* d_row_stat);
 hipError_t orbx_launch_compact(hipStream_t s, const OrbxPlan& plan, int n_frames,
                                const unsigned long long* d_mask, orbx_keypoint* d_cand, int32_t* d_cand_count,

@@ -516,7 +516,8 @@ __device__ __forceinline__ uint32_t pretest_pk(uint32_t ip, uint32_t a, uint32_t
 
 template <int R, bool WRITE_SCORES>
 __global__ __launch_bounds__(256) void k_fast_nms2(const OrbxTileDesc* __restrict__ tiles,
-                                                   const uint8_t* __restrict__ pyr, OrbxFastParams fp,
+                                                   const uint8_t* __restrict__ pyr, int frame_bytes,
+                                                   int mask_words, OrbxFastParams fp,
                                                    u64* __restrict__ mask, uint16_t* __restrict__ scores_dbg,
                                                    u64* __restrict__ row_stat) {
   constexpr int TH = ORBX_FAST_TH, TW = ORBX_FAST_TW;
@@ -530,39 +531,60 @@ __global__ __launch_bounds__(256) void k_fast_nms2(const OrbxTileDesc* __restric
   __shared__ int s_qn;
   __shared__ int s_skip;
 
-  // everything about this tile in one 64-byte scalar load (band-major order, see above)
-  const OrbxTileDesc d = tiles[blockIdx.x];
+  // everything about this tile in one 64-byte scalar load.  grid = (frames, tiles of
+  // one frame in band-major order): x is the fastest dispatch index, so band b of
+  // every frame is dispatched before band b+1 of any frame, and the 25 KB table is
+  // shared by all frames (it stays in the scalar cache).
+  const int f = blockIdx.x;
+  const OrbxTileDesc d = tiles[blockIdx.y];
   struct {
     int w, h, pitch, cap, mask_wpr;
   } L = {d.w, d.h, d.pitch, d.u0, d.u1};
-  const int tx = d.tx, ty = d.ty, tiles_x = d.u2;
-  const uint8_t* img = pyr + d.img_off;
+  // the workgroup owns the tiles tx_first .. tx_first + n_strip - 1 of tile row ty (one
+  // tile in tile row 0, a strip of tiles further down, where most workgroups only exit)
+  const int tx_first = d.tx, ty = d.ty, tiles_x = d.u2, n_strip = d.f;
+  const uint8_t* img = pyr + ((size_t)f * (size_t)frame_bytes + d.img_off);
   const int tid = threadIdx.x;
   const int thr = fp.threshold;
-  const int x0 = tx * TW, y0 = ty * TH;
+  const int y0 = ty * TH;
   const int gy0 = y0 - 3 - R;
-  u64* mrow = mask + d.mask_off;
-  u64* stat = row_stat ? row_stat + d.stat_index : nullptr;
+  u64* mrow = mask + ((size_t)f * (size_t)mask_words + d.mask_off);
+  // per frame: ORBX_MAX_LEVELS x ORBX_MAX_BANDS tile-row statistics, then one
+  // "dead from band" word per level
+  u64* fstat = row_stat ? row_stat + (size_t)f * ORBX_FAST_STAT_WORDS : nullptr;
+  u64* stat = fstat ? fstat + d.stat_index : nullptr;
+  u64* dead_from = fstat ? fstat + ORBX_MAX_LEVELS * ORBX_MAX_BANDS + d.l : nullptr;
 
-  // early exit: the tile rows above are complete and already hold >= cap survivors
+  // early exit: the tile rows above are complete and already hold >= cap survivors.
+  // An exiting tile stores nothing: its mask words are never looked at (the row-major
+  // walk of k_level_select ignores everything after the first cap survivors), and the
+  // proof for later tile rows needs only the rows above the first dead one.  The first
+  // tile that proves row b dead publishes 64-b in dead_from (monotone max), so that later
+  // tiles decide with one load.
   if (stat && ty > 0) {
     if (tid < 64) {
       u64 st = 0;
       if (tid < ty) st = __hip_atomic_load(&stat[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool complete = tid >= ty || (int)(st >> 32) == tiles_x;
-      const u64 inc = __ballot(!complete);              // rows not yet complete
-      const int k = inc ? __ffsll((long long)inc) - 1 : 64;  // first incomplete row
-      const int surv = wave_sum(tid < k && tid < ty ? (int)(uint32_t)st : 0);
-      if (tid == 0) s_skip = surv >= L.cap;
+      if (tid == 63) st = __hip_atomic_load(dead_from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int known = (int)__builtin_amdgcn_readlane((uint32_t)st, 63);  // 64 - (first dead row), 0: unknown
+      bool skip = known >= 64 - ty;
+      if (!skip) {
+        const bool complete = tid >= ty || (int)(st >> 32) == tiles_x;
+        const u64 inc = __ballot(!complete);                   // rows not yet complete
+        const int k = inc ? __ffsll((long long)inc) - 1 : 64;  // first incomplete row
+        const int surv = wave_sum(tid < k && tid < ty ? (int)(uint32_t)st : 0);
+        skip = surv >= L.cap;
+        if (skip && tid == 0)
+          __hip_atomic_fetch_max(dead_from, (u64)(64 - ty), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (tid == 0) s_skip = skip;
     }
     __syncthreads();
-    if (s_skip) {
-      if (tid < TH && y0 + tid < L.h) mrow[(size_t)(y0 + tid) * L.mask_wpr + tx] = 0ull;
-      if (tid == 0) __hip_atomic_fetch_add(&stat[ty], 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
+    if (s_skip) return;
   }
 
+  for (int tx = tx_first; tx < tx_first + n_strip; tx++) {
+  const int x0 = tx * TW;
   // phase 1: tile + halo -> LDS with aligned 8-byte loads (x0-8 is 8-byte aligned).
   // All loads of a thread are issued before the first is stored (one memory latency
   // per tile instead of one per loop iteration).
@@ -740,6 +762,8 @@ __global__ __launch_bounds__(256) void k_fast_nms2(const OrbxTileDesc* __restric
       const int gy = y0 + iy, gx = x0 + ix;
       if (gy < L.h && gx < L.w) scores_dbg[(size_t)gy * L.w + gx] = s_score[(iy + R) * F2_SC_PITCH + ix + 4];
     }
+  }
+  if (tx + 1 < tx_first + n_strip) __syncthreads();  // the LDS tiles are reused by the next tile of the strip
   }
 }
 
@@ -1203,6 +1227,15 @@ struct DescLds {
   uint16_t hs[DESC_ROWS * DESC_HP];  // horizontal 5-sums: hs[r][j] = sum patch[r][j..j+4]
 };
 
+// the four 5-byte sums b[k..k+4], k = 0..3, of the 8 bytes (d0 low), as packed u16.
+// v_qsad_pk_u16_u8 against 0 gives the four sliding 4-byte sums b[k..k+3] plus a packed
+// accumulator, which carries b[k+4]: one instruction instead of ~20 byte extracts and adds.
+__device__ __forceinline__ u64 hsum5x4(uint32_t d0, uint32_t d1) {
+  const u64 acc = (u64)__builtin_amdgcn_perm(d1, d1, 0x0c010c00u) |
+                  ((u64)__builtin_amdgcn_perm(d1, d1, 0x0c030c02u) << 32);
+  return __builtin_amdgcn_qsad_pk_u16_u8((u64)d0 | ((u64)d1 << 32), 0u, acc);
+}
+
 struct DescJob {
   const uint8_t* img;
   int w, h, pitch;
@@ -1288,11 +1321,7 @@ __device__ __forceinline__ void describe_wave(const DescJob& jb, DescLds& lds, i
     for (int k = 0; k < (DESC_ROWS * 10 + 63) / 64; k++) {
       if (lane + 64 * k < DESC_ROWS * 10) {
         const uint32_t d0 = lds.patch[r * (DESC_PITCH / 4) + g], d1 = lds.patch[r * (DESC_PITCH / 4) + g + 1];
-        const uint32_t b0 = d0 & 0xff, b1 = (d0 >> 8) & 0xff, b2 = (d0 >> 16) & 0xff, b3 = d0 >> 24;
-        const uint32_t b4 = d1 & 0xff, b5 = (d1 >> 8) & 0xff, b6 = (d1 >> 16) & 0xff, b7 = d1 >> 24;
-        const uint32_t s0 = b0 + b1 + b2 + b3 + b4;
-        const uint32_t s1 = s0 - b0 + b5, s2 = s1 - b1 + b6, s3 = s2 - b2 + b7;
-        *reinterpret_cast<uint2*>(&lds.hs[r * DESC_HP + 4 * g]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+        *reinterpret_cast<u64*>(&lds.hs[r * DESC_HP + 4 * g]) = hsum5x4(d0, d1);
       }
       r += 6;
       g += 4;
@@ -1440,11 +1469,7 @@ __device__ __forceinline__ void desc_box_tables(DescLds& lds, int lane) {
     for (int k = 0; k < (DESC_ROWS * 10 + 63) / 64; k++) {
       if (lane + 64 * k < DESC_ROWS * 10) {
         const uint32_t d0 = lds.patch[r * (DESC_PITCH / 4) + g], d1 = lds.patch[r * (DESC_PITCH / 4) + g + 1];
-        const uint32_t b0 = d0 & 0xff, b1 = (d0 >> 8) & 0xff, b2 = (d0 >> 16) & 0xff, b3 = d0 >> 24;
-        const uint32_t b4 = d1 & 0xff, b5 = (d1 >> 8) & 0xff, b6 = (d1 >> 16) & 0xff, b7 = d1 >> 24;
-        const uint32_t s0 = b0 + b1 + b2 + b3 + b4;
-        const uint32_t s1 = s0 - b0 + b5, s2 = s1 - b1 + b6, s3 = s2 - b2 + b7;
-        *reinterpret_cast<uint2*>(&lds.hs[r * DESC_HP + 4 * g]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+        *reinterpret_cast<u64*>(&lds.hs[r * DESC_HP + 4 * g]) = hsum5x4(d0, d1);
       }
       r += 6;
       g += 4;
@@ -1479,6 +1504,14 @@ __device__ __forceinline__ void desc_box_tables(DescLds& lds, int lane) {
     }
   }
   wave_lds_sync();
+}
+
+// lroundf (half away from zero) with a float result, for |v| < 2^22: trunc(v) + trunc(2 * (v - trunc(v)));
+// every step is exact, so this equals orbx_lroundf
+__device__ __forceinline__ float lround_f(float v) {
+  const float t = __builtin_truncf(v);
+  const float fr = __fsub_rn(v, t);
+  return __fadd_rn(t, __builtin_truncf(__fadd_rn(fr, fr)));
 }
 
 __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t* __restrict__ pyr, int patch_size,
@@ -1584,7 +1617,17 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
   }
   __syncthreads();
 
-  // pass C: descriptors (the patches are still in registers)
+  // pass C: descriptors (the patches are still in registers).  A lane evaluates the same
+  // four tests for every keypoint: its pattern points are converted to float once.
+  float pat[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int32_t pk = reinterpret_cast<const int32_t*>(c_pattern)[k * 64 + lane];
+    pat[k][0] = (float)(int8_t)(pk & 0xff);
+    pat[k][1] = (float)(int8_t)((pk >> 8) & 0xff);
+    pat[k][2] = (float)(int8_t)((pk >> 16) & 0xff);
+    pat[k][3] = (float)(int8_t)((pk >> 24) & 0xff);
+  }
 #pragma unroll
   for (int j = 0; j < DESC_KPW; j++) {
     if (j < nk) {
@@ -1597,25 +1640,36 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
       // every rotated centre is within 18 px of the keypoint; with a 20 px margin no test can be skipped
       const bool interior = jb.x >= DESC_R && jb.y >= DESC_R && jb.x < jb.w - DESC_R && jb.y < jb.h - DESC_R;
       u64 d[4];
+      if (interior) {
+        // no test can be skipped: lround as float arithmetic (trunc(v) + trunc(2 * frac), exact), the
+        // table index as one exact fma, the constant part of the index in the instruction offset
+        const uint16_t* tbl = &lds.box[18 * DESC_HP + 18 + off];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int i = k * 64 + lane;
-        const int32_t pk = reinterpret_cast<const int32_t*>(c_pattern)[i];
-        const float x1 = (float)(int8_t)(pk & 0xff), y1 = (float)(int8_t)((pk >> 8) & 0xff);
-        const float x2 = (float)(int8_t)((pk >> 16) & 0xff), y2 = (float)(int8_t)((pk >> 24) & 0xff);
-        const int dx1 = orbx_lroundf(__fsub_rn(__fmul_rn(c, x1), __fmul_rn(s, y1)));
-        const int dy1 = orbx_lroundf(__fadd_rn(__fmul_rn(s, x1), __fmul_rn(c, y1)));
-        const int dx2 = orbx_lroundf(__fsub_rn(__fmul_rn(c, x2), __fmul_rn(s, y2)));
-        const int dy2 = orbx_lroundf(__fadd_rn(__fmul_rn(s, x2), __fmul_rn(c, y2)));
-        bool ok = true;
-        if (!interior) {
-          const int cx1 = jb.x + dx1, cy1 = jb.y + dy1, cx2 = jb.x + dx2, cy2 = jb.y + dy2;
-          ok = !(cx1 < 2 || cy1 < 2 || cx1 > jb.w - 1 || cy1 > jb.h - 1 || cx2 < 2 || cy2 < 2 || cx2 > jb.w - 1 ||
-                 cy2 > jb.h - 1);
+        for (int k = 0; k < 4; k++) {
+          const float x1 = pat[k][0], y1 = pat[k][1], x2 = pat[k][2], y2 = pat[k][3];
+          const float fx1 = lround_f(__fsub_rn(__fmul_rn(c, x1), __fmul_rn(s, y1)));
+          const float fy1 = lround_f(__fadd_rn(__fmul_rn(s, x1), __fmul_rn(c, y1)));
+          const float fx2 = lround_f(__fsub_rn(__fmul_rn(c, x2), __fmul_rn(s, y2)));
+          const float fy2 = lround_f(__fadd_rn(__fmul_rn(s, x2), __fmul_rn(c, y2)));
+          const int i1 = (int)__builtin_fmaf(fy1, (float)DESC_HP, fx1);
+          const int i2 = (int)__builtin_fmaf(fy2, (float)DESC_HP, fx2);
+          d[k] = __ballot(tbl[i1] < tbl[i2]);
         }
-        const int s1 = lds.box[(dy1 + 18) * DESC_HP + dx1 + 18 + off];
-        const int s2 = lds.box[(dy2 + 18) * DESC_HP + dx2 + 18 + off];
-        d[k] = __ballot(ok && s1 < s2);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float x1 = pat[k][0], y1 = pat[k][1], x2 = pat[k][2], y2 = pat[k][3];
+          const int dx1 = orbx_lroundf(__fsub_rn(__fmul_rn(c, x1), __fmul_rn(s, y1)));
+          const int dy1 = orbx_lroundf(__fadd_rn(__fmul_rn(s, x1), __fmul_rn(c, y1)));
+          const int dx2 = orbx_lroundf(__fsub_rn(__fmul_rn(c, x2), __fmul_rn(s, y2)));
+          const int dy2 = orbx_lroundf(__fadd_rn(__fmul_rn(s, x2), __fmul_rn(c, y2)));
+          const int cx1 = jb.x + dx1, cy1 = jb.y + dy1, cx2 = jb.x + dx2, cy2 = jb.y + dy2;
+          const bool ok = !(cx1 < 2 || cy1 < 2 || cx1 > jb.w - 1 || cy1 > jb.h - 1 || cx2 < 2 || cy2 < 2 ||
+                            cx2 > jb.w - 1 || cy2 > jb.h - 1);
+          const int s1 = lds.box[(dy1 + 18) * DESC_HP + dx1 + 18 + off];
+          const int s2 = lds.box[(dy2 + 18) * DESC_HP + dx2 + 18 + off];
+          d[k] = __ballot(ok && s1 < s2);
+        }
       }
       wave_lds_sync();
       if (lane == 0) {
@@ -1825,35 +1879,38 @@ hipError_t orbx_launch_blur2(hipStream_t s, const OrbxTileDesc* d_tiles, int n_t
 }
 
 template <int R>
-static void launch_fast2(dim3 grid, hipStream_t s, const OrbxTileDesc* d_tiles, const uint8_t* d_pyr,
-                         OrbxFastParams fp, unsigned long long* d_mask, uint16_t* d_scores_dbg,
+static void launch_fast2(dim3 grid, hipStream_t s, const OrbxTileDesc* d_tiles, const uint8_t* d_pyr, int frame_bytes,
+                         int mask_words, OrbxFastParams fp, unsigned long long* d_mask, uint16_t* d_scores_dbg,
                          unsigned long long* d_row_stat) {
   if (d_scores_dbg)
-    hipLaunchKernelGGL((k_fast_nms2<R, true>), grid, dim3(256), 0, s, d_tiles, d_pyr, fp, d_mask, d_scores_dbg,
-                       d_row_stat);
+    hipLaunchKernelGGL((k_fast_nms2<R, true>), grid, dim3(256), 0, s, d_tiles, d_pyr, frame_bytes, mask_words, fp,
+                       d_mask, d_scores_dbg, d_row_stat);
   else
-    hipLaunchKernelGGL((k_fast_nms2<R, false>), grid, dim3(256), 0, s, d_tiles, d_pyr, fp, d_mask, d_scores_dbg,
-                       d_row_stat);
+    hipLaunchKernelGGL((k_fast_nms2<R, false>), grid, dim3(256), 0, s, d_tiles, d_pyr, frame_bytes, mask_words, fp,
+                       d_mask, d_scores_dbg, d_row_stat);
 }
 
-// d_row_stat: n_frames * ORBX_MAX_LEVELS * ORBX_MAX_BANDS zeroed u64 (or NULL: no early exit)
-hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, const uint8_t* d_pyr,
-                                OrbxFastParams fp, unsigned long long* d_mask, uint16_t* d_scores_dbg,
+// d_tiles: the n_tiles tiles of ONE frame in band-major order; grid = (frames, tiles).
+// d_row_stat: n_frames * ORBX_FAST_STAT_WORDS zeroed u64 (or NULL: no early exit)
+hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int n_frames,
+                                const uint8_t* d_pyr, int frame_bytes, int mask_words, OrbxFastParams fp,
+                                unsigned long long* d_mask, uint16_t* d_scores_dbg,
                                 unsigned long long* d_row_stat) {
-  if (n_tiles <= 0) return hipSuccess;
-  dim3 grid(n_tiles);
+  if (n_tiles <= 0 || n_frames <= 0) return hipSuccess;
+  if (n_tiles > 65535) return hipErrorInvalidValue;
+  dim3 grid(n_frames, n_tiles);
   switch (fp.nms_radius) {
     case 0:
-      launch_fast2<0>(grid, s, d_tiles, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
+      launch_fast2<0>(grid, s, d_tiles, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores_dbg, d_row_stat);
       break;
     case 1:
-      launch_fast2<1>(grid, s, d_tiles, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
+      launch_fast2<1>(grid, s, d_tiles, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores_dbg, d_row_stat);
       break;
     case 2:
-      launch_fast2<2>(grid, s, d_tiles, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
+      launch_fast2<2>(grid, s, d_tiles, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores_dbg, d_row_stat);
       break;
     default:
-      launch_fast2<3>(grid, s, d_tiles, d_pyr, fp, d_mask, d_scores_dbg, d_row_stat);
+      launch_fast2<3>(grid, s, d_tiles, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores_dbg, d_row_stat);
       break;
   }
   return ORBX_LAUNCH_CHECK();

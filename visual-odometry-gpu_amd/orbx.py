@@ -28,7 +28,7 @@ EXPORTS = [
     "orbx_last_error_string", "orbx_status_string", "orbx_version", "orbx_get_plan",
     "orbx_detect_and_compute", "orbx_detect_and_compute_batch_device", "orbx_detect_and_compute_batch_host",
     "orbx_wait", "orbx_batch_results_device", "orbx_batch_fetch", "orbx_enable_stage_timing",
-    "orbx_last_stage_times", "orbx_stage_times_history", "orbx_bench_stage", "orbx_set_fast_early_exit", "orbx_fast_score", "orbx_nms", "orbx_fast",
+    "orbx_last_stage_times", "orbx_stage_times_history", "orbx_bench_stage", "orbx_set_fast_early_exit", "orbx_fast_tile_counts", "orbx_fast_score", "orbx_nms", "orbx_fast",
     "orbx_orientations", "orbx_brief", "orbx_harris", "orbx_blur5_sep", "orbx_blur5_273", "orbx_conv2d",
     "orbx_gaussian_blur_conv", "orbx_gaussian_kernel", "orbx_sobel", "orbx_build_pyramid_level",
     "orbx_select_top", "orbx_knn2", "orbx_match_ratio", "orbx_batch_match_consecutive", "orbx_batch_match_fetch",
@@ -257,6 +257,12 @@ class Context:
 
     def set_fast_early_exit(self, on=True):
         self._chk(self._lib.orbx_set_fast_early_exit(self._h, 1 if on else 0))
+
+    def fast_tile_counts(self):
+        """(tiles that did the full FAST/NMS work, all tiles) of the last whole-path batch."""
+        w, t = C.c_longlong(0), C.c_longlong(0)
+        self._chk(self._lib.orbx_fast_tile_counts(self._h, C.byref(w), C.byref(t)))
+        return w.value, t.value
 
     def last_stage_times(self, back=0):
         """Stage times (ms) of the timed batched call `back` calls ago; call wait() first."""
