@@ -1528,6 +1528,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
   __shared__ __attribute__((aligned(16))) DescLds s_lds[4];
   __shared__ int s_m[DESC_KPB][2];
   __shared__ float s_cs[DESC_KPB][2];
+  __shared__ uint2 s_mw[4 * (DESC_PITCH / 4)];
   const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // Final keypoint order = levels back to back (src/orb.cpp:100-102).  The selection
@@ -1543,9 +1544,44 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
   const int slot0 = blockIdx.x * DESC_KPB;
   if (slot0 >= count) return;  // whole workgroup
   DescLds& lds = s_lds[wave];
-  const uint8_t* s_patch = reinterpret_cast<const uint8_t*>(lds.patch);
+  const int pr = patch_size / 2;
+  // moment weights of the four bytes of patch dword column c when the keypoint's patch starts
+  // `off` bytes into its first dword: {x - x_kp + pr for bytes inside the orientation window
+  // (else 0), 1 for bytes inside the window (else 0)}, for v_dot4_u32_u8
+  if (tid < 4 * (DESC_PITCH / 4)) {
+    const int off = tid / (DESC_PITCH / 4), c = tid - off * (DESC_PITCH / 4);
+    uint32_t xw = 0, on = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int t = 4 * c + b - off - (DESC_R - pr);
+      if (t >= 0 && t <= 2 * pr) {
+        xw |= (uint32_t)t << (8 * b);
+        on |= 1u << (8 * b);
+      }
+    }
+    s_mw[tid] = make_uint2(xw, on);
+  }
+  // keypoint-independent geometry of the DESC_NLD patch dwords a lane holds: dword
+  // lane + 64k is (row rowk[k], dword column (c0 + 4k) mod 12)
+  int rowk[DESC_NLD], c3[3];
+  uint32_t rin = 0;  // bit k: the dword exists and its row is inside the orientation window
+  {
+    int row = lane / (DESC_PITCH / 4), c = lane - row * (DESC_PITCH / 4);
+#pragma unroll
+    for (int k = 0; k < DESC_NLD; k++) {
+      rowk[k] = row;
+      if (k < 3) c3[k] = c;
+      if (lane + 64 * k < DESC_ROWS * (DESC_PITCH / 4) && row >= DESC_R - pr && row <= DESC_R + pr) rin |= 1u << k;
+      row += 5;
+      c += 4;
+      if (c >= DESC_PITCH / 4) {
+        c -= DESC_PITCH / 4;
+        row += 1;
+      }
+    }
+  }
+  __syncthreads();
   const size_t fo = (size_t)f * plan.out_cap;
-  const int pr = patch_size / 2, P = 2 * pr + 1;
 
   // this wave's keypoints; all their patches are requested before the first is used
   const int nk = min(DESC_KPW, max(0, count - (slot0 + wave * DESC_KPW)));  // wave-uniform
@@ -1571,7 +1607,23 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
     }
   }
 #pragma unroll
-  for (int j = 0; j < DESC_KPW; j++) desc_fetch_patch(jobs[j], lane, regs[j], offs[j]);
+  for (int j = 0; j < DESC_KPW; j++) {
+    const DescJob& jb = jobs[j];
+    const int py0 = jb.y - DESC_R, ax0 = (jb.x - DESC_R) & ~3;
+    // wave-uniform: every dword of the 41 x 48 neighbourhood lies inside the (zero-padded) level
+    if (py0 >= 0 && py0 + DESC_ROWS <= jb.h && ax0 >= 0 && ax0 + DESC_PITCH <= jb.pitch) {
+      offs[j] = jb.x - DESC_R - ax0;
+      const uint32_t base = (uint32_t)(py0 * jb.pitch + ax0);
+#pragma unroll
+      for (int k = 0; k < DESC_NLD; k++) {
+        regs[j][k] = 0;
+        if (lane + 64 * k < DESC_ROWS * (DESC_PITCH / 4))
+          regs[j][k] = *reinterpret_cast<const uint32_t*>(jb.img + (base + (uint32_t)(rowk[k] * jb.pitch + 4 * c3[k % 3])));
+      }
+    } else {
+      desc_fetch_patch(jb, lane, regs[j], offs[j]);
+    }
+  }
 
   // pass A: moments
 #pragma unroll
@@ -1582,23 +1634,22 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
       int m10 = 0, m01 = 0;
       // full patch must lie inside the image, else angle 0 (src/orb_cpu.cpp:152-156)
       if (!(jb.x - pr < 0 || jb.x + pr >= jb.w || jb.y - pr < 0 || jb.y + pr >= jb.h)) {
-        desc_store_patch(lds, lane, regs[j]);
-        wave_lds_sync();
-        const int grp_shift = P <= 32 ? 5 : 6;
-        const int col = lane & ((1 << grp_shift) - 1), grp = lane >> grp_shift, ngrp = 64 >> grp_shift;
-        int colsum = 0;
-        if (col < P) {
-          const uint8_t* pc = s_patch + (DESC_R - pr) * DESC_PITCH + (col - pr + DESC_R + off);
-#pragma unroll 4
-          for (int rr = grp; rr < P; rr += ngrp) {
-            const int I = pc[rr * DESC_PITCH];
-            colsum += I;
-            m01 += (rr - pr) * I;
-          }
+        // straight from the registers: per dword one dot product with the x weights and one
+        // with the window mask; exact integers (< 2^24, like the reference's float sums)
+        uint2 mw[3];
+#pragma unroll
+        for (int m = 0; m < 3; m++) mw[m] = s_mw[off * (DESC_PITCH / 4) + c3[m]];
+        uint32_t X = 0, S = 0, M = 0;
+#pragma unroll
+        for (int k = 0; k < DESC_NLD; k++) {
+          const uint32_t z = regs[j][k] & (uint32_t)(-(int32_t)((rin >> k) & 1u));
+          X = __builtin_amdgcn_udot4(z, mw[k % 3].x, X, false);
+          const uint32_t rs = __builtin_amdgcn_udot4(z, mw[k % 3].y, 0u, false);
+          S += rs;
+          M += (uint32_t)rowk[k] * rs;
         }
-        m10 = wave_sum((col - pr) * colsum);
-        m01 = wave_sum(m01);
-        wave_lds_sync();
+        m10 = wave_sum((int)X - pr * (int)S);
+        m01 = wave_sum((int)M - DESC_R * (int)S);
       }
       if (lane == 0) {
         s_m[q][0] = m10;
