@@ -859,7 +859,10 @@ __device__ __forceinline__ float harris_at(const uint8_t* img, int w, int h, int
   return __fsub_rn(det, __fmul_rn(__fmul_rn(kk, trace), trace));
 }
 
-// Fast path for interior keypoints and window K <= 7: the (K+2)^2 pixel
+// Fast path for window K <= 7 and keypoints whose (K+2)^2 pixel neighbourhood leaves
+// the image by at most ONE row / column (FAST keypoints keep 3 px from the border,
+// so with K = 7 that is every keypoint of the whole path; the reflected row is a
+// different row pointer, the reflected column one v_perm per row): the
 // neighbourhood is fetched once with 3 aligned dword loads per row and
 // byte-aligned in registers (v_alignbyte), pixels are converted with
 // v_cvt_f32_ubyteN, Sobel sums are shared between neighbouring taps.  Every
@@ -870,22 +873,34 @@ template <int K>
 __device__ __forceinline__ float harris_fast(const uint8_t* img, int w, int h, int pitch, int x, int y,
                                              const float* __restrict__ g, float kk) {
   constexpr int r = K / 2, P = K + 2;
-  const int xs = x - r - 1;
-  const int a0 = xs & ~3, off = xs - a0;
+  static_assert(P <= 9, "the third dword of a row supplies pixel 8 only");
+  const int xs = x - r - 1;               // >= -1
+  const int a0 = xs & ~3, off = xs - a0;  // xs == -1: a0 = -4, off = 3
+  // BORDER_REFLECT_101 of the one column that may lie outside: pixel -1 is pixel 1
+  // (byte 2 of the first aligned group), pixel w is pixel w-2 (byte 2 of the second)
+  const uint32_t sel_l = xs < 0 ? 0x03020102u : 0x03020100u;
+  const uint32_t sel_r = xs + P - 1 >= w ? 0x0c0c0c06u : 0x0c0c0c00u;
   // all (K+2) x 3 dword loads first (one memory latency), then the window is
   // consumed row by row with three rolling pixel rows / horizontal sums, which
   // keeps the live set around 100 VGPRs instead of 160+
   uint32_t raw[P][3];
 #pragma unroll
   for (int i = 0; i < P; i++) {
-    const uint32_t* row = reinterpret_cast<const uint32_t*>(img + (size_t)(y - r - 1 + i) * pitch + a0);
-    raw[i][0] = row[0];
-    raw[i][1] = row[1];
-    raw[i][2] = row[2];
+    int yy = y - r - 1 + i;  // only the first / last row can be outside (by one)
+    if (i == 0) yy = yy < 0 ? 1 : yy;
+    if (i == P - 1) yy = yy >= h ? h - 2 : yy;
+    const int o = yy * pitch + a0;
+    // o == -4 only in row 0 with the left column reflected; that dword supplies nothing
+    // but the replaced pixel, so any readable address will do
+    raw[i][0] = *reinterpret_cast<const uint32_t*>(img + max(o, 0));
+    raw[i][1] = *reinterpret_cast<const uint32_t*>(img + (o + 4));
+    raw[i][2] = *reinterpret_cast<const uint32_t*>(img + (o + 8));  // may run into the next row / the pool's tail slack
   }
   auto cvt_row = [&](int i, float (&out)[P]) {
-    const uint32_t q[3] = {__builtin_amdgcn_alignbyte(raw[i][1], raw[i][0], off),
-                           __builtin_amdgcn_alignbyte(raw[i][2], raw[i][1], off), raw[i][2] >> (8 * off)};
+    uint32_t q[3] = {__builtin_amdgcn_alignbyte(raw[i][1], raw[i][0], off),
+                     __builtin_amdgcn_alignbyte(raw[i][2], raw[i][1], off), raw[i][2] >> (8 * off)};
+    q[2] = __builtin_amdgcn_perm(q[1], q[2], sel_r);
+    q[0] = __builtin_amdgcn_perm(q[0], q[0], sel_l);
 #pragma unroll
     for (int j = 0; j < P; j++) out[j] = (float)((q[j >> 2] >> (8 * (j & 3))) & 0xffu);
   };
@@ -927,8 +942,8 @@ __device__ __forceinline__ float harris_fast(const uint8_t* img, int w, int h, i
 
 __device__ __forceinline__ float harris_any(const uint8_t* img, int w, int h, int pitch, int x, int y,
                                             const float* __restrict__ g, int K, float kk) {
-  const int m = K / 2 + 1;  // the fast path needs the whole (K+2)^2 window inside the image
-  if (x >= m && y >= m && x < w - m && y < h - m) {
+  const int m = K / 2 + 1;  // the fast path takes (K+2)^2 windows that leave the image by at most one pixel
+  if (x >= m - 1 && y >= m - 1 && x <= w - m && y <= h - m && w >= 4 && h >= 4) {
     if (K == 7) return harris_fast<7>(img, w, h, pitch, x, y, g, kk);
     if (K == 5) return harris_fast<5>(img, w, h, pitch, x, y, g, kk);
     if (K == 3) return harris_fast<3>(img, w, h, pitch, x, y, g, kk);
@@ -1083,7 +1098,7 @@ __global__ __launch_bounds__(256) void k_harris2_flat(const uint8_t* __restrict_
 // + quota_l) of the frame (out_off_l = sum of the lower levels' quotas) plus a
 // per-level count; k_describe2 compacts them into the final order.
 #define LVL_THREADS 512
-__global__ __launch_bounds__(LVL_THREADS) void k_level_select(OrbxPlan plan, int mode, const u64* __restrict__ mask,
+__global__ __launch_bounds__(LVL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_level_select(OrbxPlan plan, int mode, const u64* __restrict__ mask,
                                                               const uint8_t* __restrict__ pyr,
                                                               const float* __restrict__ gauss, int K, float kk,
                                                               orbx_keypoint* __restrict__ sel_lkp,
@@ -1134,7 +1149,7 @@ __global__ __launch_bounds__(LVL_THREADS) void k_level_select(OrbxPlan plan, int
   const size_t so = (size_t)f * plan.out_cap + L.out_off;
   if (tid == 0) sel_count[f * plan.nlevels + l] = keep;
 
-  if (mode == ORBX_SELECT_ROWMAJOR) {
+  if ((mode & 0xff) == ORBX_SELECT_ROWMAJOR) {
     for (int i = tid; i < keep; i += LVL_THREADS) {
       const uint32_t p = s_kp[i];
       orbx_keypoint kp;
@@ -1153,7 +1168,7 @@ __global__ __launch_bounds__(LVL_THREADS) void k_level_select(OrbxPlan plan, int
     u64 key = 0ull;  // padding: the smallest key, never outranks anything
     if (i < n) {
       const uint32_t p = s_kp[i];
-      const float r = harris_any(img, L.w, L.h, L.pitch, (int)(p & 0xffffu), (int)(p >> 16), gauss, K, kk);
+      const float r = (mode & 0x200) ? 0.0f : harris_any(img, L.w, L.h, L.pitch, (int)(p & 0xffffu), (int)(p >> 16), gauss, K, kk);
       s_r[i] = r;
       uint32_t u = orbx_f2u(r);
       if (u == 0x80000000u) u = 0u;
@@ -1165,6 +1180,7 @@ __global__ __launch_bounds__(LVL_THREADS) void k_level_select(OrbxPlan plan, int
   __syncthreads();
 
   // phase 3: rank and scatter
+  if (mode & 0x100) return;
   for (int i = tid; i < n; i += LVL_THREADS) {
     const u64 ki = s_key[i];
     int rank = 0;
@@ -1514,6 +1530,13 @@ __device__ __forceinline__ float lround_f(float v) {
   return __fadd_rn(t, __builtin_truncf(__fadd_rn(fr, fr)));
 }
 
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2_t lround_f2(f2_t v) {
+  const f2_t t = __builtin_elementwise_trunc(v);
+  const f2_t fr = v - t;
+  return t + __builtin_elementwise_trunc(fr + fr);
+}
+
 __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t* __restrict__ pyr, int patch_size,
                                                    const int32_t* __restrict__ sel_count,
                                                    const orbx_keypoint* __restrict__ sel_lkp,
@@ -1670,14 +1693,12 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
 
   // pass C: descriptors (the patches are still in registers).  A lane evaluates the same
   // four tests for every keypoint: its pattern points are converted to float once.
-  float pat[4][4];
+  f2_t patx[4], paty[4];  // {x1, x2}, {y1, y2} of test 64k + lane
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int32_t pk = reinterpret_cast<const int32_t*>(c_pattern)[k * 64 + lane];
-    pat[k][0] = (float)(int8_t)(pk & 0xff);
-    pat[k][1] = (float)(int8_t)((pk >> 8) & 0xff);
-    pat[k][2] = (float)(int8_t)((pk >> 16) & 0xff);
-    pat[k][3] = (float)(int8_t)((pk >> 24) & 0xff);
+    patx[k] = f2_t{(float)(int8_t)(pk & 0xff), (float)(int8_t)((pk >> 16) & 0xff)};
+    paty[k] = f2_t{(float)(int8_t)((pk >> 8) & 0xff), (float)(int8_t)((pk >> 24) & 0xff)};
   }
 #pragma unroll
   for (int j = 0; j < DESC_KPW; j++) {
@@ -1695,21 +1716,21 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
         // no test can be skipped: lround as float arithmetic (trunc(v) + trunc(2 * frac), exact), the
         // table index as one exact fma, the constant part of the index in the instruction offset
         const uint16_t* tbl = &lds.box[18 * DESC_HP + 18 + off];
+        // both points of a test side by side in the packed-f32 lanes (v_pk_mul/add/fma_f32);
+        // no contraction (the TU is built with -ffp-contract=off), so each product and sum
+        // rounds like the reference's scalar code
+        const f2_t C2 = {c, c}, S2 = {s, s}, HP2 = {(float)DESC_HP, (float)DESC_HP};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const float x1 = pat[k][0], y1 = pat[k][1], x2 = pat[k][2], y2 = pat[k][3];
-          const float fx1 = lround_f(__fsub_rn(__fmul_rn(c, x1), __fmul_rn(s, y1)));
-          const float fy1 = lround_f(__fadd_rn(__fmul_rn(s, x1), __fmul_rn(c, y1)));
-          const float fx2 = lround_f(__fsub_rn(__fmul_rn(c, x2), __fmul_rn(s, y2)));
-          const float fy2 = lround_f(__fadd_rn(__fmul_rn(s, x2), __fmul_rn(c, y2)));
-          const int i1 = (int)__builtin_fmaf(fy1, (float)DESC_HP, fx1);
-          const int i2 = (int)__builtin_fmaf(fy2, (float)DESC_HP, fx2);
-          d[k] = __ballot(tbl[i1] < tbl[i2]);
+          const f2_t X = patx[k], Y = paty[k];
+          const f2_t rx = lround_f2(C2 * X - S2 * Y), ry = lround_f2(S2 * X + C2 * Y);
+          const f2_t idx = __builtin_elementwise_fma(ry, HP2, rx);
+          d[k] = __ballot(tbl[(int)idx.x] < tbl[(int)idx.y]);
         }
       } else {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const float x1 = pat[k][0], y1 = pat[k][1], x2 = pat[k][2], y2 = pat[k][3];
+          const float x1 = patx[k].x, y1 = paty[k].x, x2 = patx[k].y, y2 = paty[k].y;
           const int dx1 = orbx_lroundf(__fsub_rn(__fmul_rn(c, x1), __fmul_rn(s, y1)));
           const int dy1 = orbx_lroundf(__fadd_rn(__fmul_rn(s, x1), __fmul_rn(c, y1)));
           const int dx2 = orbx_lroundf(__fsub_rn(__fmul_rn(c, x2), __fmul_rn(s, y2)));
@@ -1984,6 +2005,7 @@ hipError_t orbx_launch_level_select(hipStream_t s, const OrbxPlan& plan, int n_f
   for (int l = 0; l < plan.nlevels; l++) maxcap = plan.L[l].cap > maxcap ? plan.L[l].cap : maxcap;
   const size_t lds = (size_t)((maxcap + 1) & ~1) * 16;
   dim3 grid(plan.nlevels, n_frames);
+  if (const char* e = getenv("ORBX_SELECT_ABLATE")) mode |= atoi(e) << 8;  // TEMP diagnostics
   hipLaunchKernelGGL(k_level_select, grid, dim3(LVL_THREADS), lds, s, plan, mode, d_mask, d_pyr, d_gauss, window, k,
                      d_sel_lkp, d_sel_resp, d_sel_count);
   return ORBX_LAUNCH_CHECK();
