@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(LVL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   const size_t so = (size_t)f * plan.out_cap + L.out_off;
   if (tid == 0) sel_count[f * plan.nlevels + l] = keep;
 
-  if ((mode & 0xff) == ORBX_SELECT_ROWMAJOR) {
+  if (mode == ORBX_SELECT_ROWMAJOR) {
     for (int i = tid; i < keep; i += LVL_THREADS) {
       const uint32_t p = s_kp[i];
       orbx_keypoint kp;
@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(LVL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     u64 key = 0ull;  // padding: the smallest key, never outranks anything
     if (i < n) {
       const uint32_t p = s_kp[i];
-      const float r = (mode & 0x200) ? 0.0f : harris_any(img, L.w, L.h, L.pitch, (int)(p & 0xffffu), (int)(p >> 16), gauss, K, kk);
+      const float r = harris_any(img, L.w, L.h, L.pitch, (int)(p & 0xffffu), (int)(p >> 16), gauss, K, kk);
       s_r[i] = r;
       uint32_t u = orbx_f2u(r);
       if (u == 0x80000000u) u = 0u;
@@ -1180,7 +1180,6 @@ __global__ __launch_bounds__(LVL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   __syncthreads();
 
   // phase 3: rank and scatter
-  if (mode & 0x100) return;
   for (int i = tid; i < n; i += LVL_THREADS) {
     const u64 ki = s_key[i];
     int rank = 0;
@@ -1537,7 +1536,7 @@ __device__ __forceinline__ f2_t lround_f2(f2_t v) {
   return t + __builtin_elementwise_trunc(fr + fr);
 }
 
-__global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t* __restrict__ pyr, int patch_size,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_describe2(OrbxPlan plan, const uint8_t* __restrict__ pyr, int patch_size,
                                                    const int32_t* __restrict__ sel_count,
                                                    const orbx_keypoint* __restrict__ sel_lkp,
                                                    const float* __restrict__ sel_resp,
@@ -1556,13 +1555,11 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // Final keypoint order = levels back to back (src/orb.cpp:100-102).  The selection
   // kernel left level l's keypoints in static slots; the prefix sums of the per-level
-  // counts (one small load, wave-uniform arithmetic) map an output slot to them.
-  int pre[ORBX_MAX_LEVELS + 1];
-  pre[0] = 0;
-#pragma unroll
-  for (int i = 0; i < ORBX_MAX_LEVELS; i++)
-    pre[i + 1] = pre[i] + (i < plan.nlevels ? sel_count[f * plan.nlevels + i] : 0);
-  const int count = pre[ORBX_MAX_LEVELS];
+  // counts (lane l holds level l: one load, one DPP scan) map an output slot to them.
+  static_assert(ORBX_MAX_LEVELS <= 64, "one lane per level");
+  const int lvl_cnt = lane < plan.nlevels ? sel_count[f * plan.nlevels + lane] : 0;
+  const int lvl_end = wave_scan_incl(lvl_cnt);  // slots of levels 0..lane
+  const int count = __builtin_amdgcn_readlane(lvl_end, 63);
   if (blockIdx.x == 0 && tid == 0) out_count[f] = count;
   const int slot0 = blockIdx.x * DESC_KPB;
   if (slot0 >= count) return;  // whole workgroup
@@ -1615,11 +1612,10 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
 #pragma unroll
   for (int j = 0; j < DESC_KPW; j++) {
     const int slot = min(slot0 + wave * DESC_KPW + j, count - 1);
-    int level = 0;
-#pragma unroll
-    for (int i = 1; i < ORBX_MAX_LEVELS; i++)
-      if (slot >= pre[i] && i < plan.nlevels) level = i;
-    const size_t src = fo + plan.L[level].out_off + (slot - pre[level]);
+    // level = number of levels that end at or before the slot (count > slot, so it is < nlevels)
+    const int level = __popcll(__ballot(lvl_end <= slot));
+    const int lvl_begin = __builtin_amdgcn_readlane(lvl_end - lvl_cnt, level);
+    const size_t src = fo + plan.L[level].out_off + (slot - lvl_begin);
     const orbx_keypoint kp = sel_lkp[src];
     jobs[j] = desc_job(plan, pyr, f, kp, level);
     scale[j] = plan.L[level].scale;
@@ -2005,7 +2001,6 @@ hipError_t orbx_launch_level_select(hipStream_t s, const OrbxPlan& plan, int n_f
   for (int l = 0; l < plan.nlevels; l++) maxcap = plan.L[l].cap > maxcap ? plan.L[l].cap : maxcap;
   const size_t lds = (size_t)((maxcap + 1) & ~1) * 16;
   dim3 grid(plan.nlevels, n_frames);
-  if (const char* e = getenv("ORBX_SELECT_ABLATE")) mode |= atoi(e) << 8;  // TEMP diagnostics
   hipLaunchKernelGGL(k_level_select, grid, dim3(LVL_THREADS), lds, s, plan, mode, d_mask, d_pyr, d_gauss, window, k,
                      d_sel_lkp, d_sel_resp, d_sel_count);
   return ORBX_LAUNCH_CHECK();
