@@ -3,6 +3,7 @@
 // (x,y) and print the Hamming distance of the descriptors") turned into a real
 // test of the C++ host mirror (visual-odometry-gpu_amd/host/orb.hpp), with the
 // CPU oracle as the checker.  Usage: test_host_mirror <raw-u8-file> <w> <h>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -172,6 +173,53 @@ int main(int argc, char** argv) {
     EXPECT(bad == 0, "%d knnMatch mismatches", bad);
     EXPECT((int)rm.size() == good && good > 100, "ratio matches %zu vs %d", rm.size(), good);
     std::printf("HammingMatcher: %zu x %zu descriptors, %d ratio matches\n", d1.size(), d2.size(), good);
+  }
+  // ---- cv::Feature2D-shaped adapter + VisualOdom::get_matches (feature_tracking.cpp:31,61; feature_matching.cpp:155-183)
+  {
+    std::vector<uint8_t> px2(px);
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) px2[(size_t)y * w + x] = px[(size_t)((y + 2) % h) * w + (x + 3) % w];
+    auto orb = orbx::Feature2D::create(1000);
+    std::vector<orbx::KeyPoint> kp1, kp2, kd;
+    orbx::DescriptorMat des1, des2;
+    orb->detectAndCompute(image, kp1, des1);
+    // same results as the reference-shaped ORB class, in cv::KeyPoint conventions
+    ORB ref(1000);
+    std::vector<Keypoint> k;
+    std::vector<float> a, r;
+    std::vector<ORBDescriptor> d;
+    std::vector<int32_t> lv;
+    ref.detectAndCompute(image, k, a, d, &r, &lv);
+    EXPECT(kp1.size() == k.size() && des1.rows == (int)k.size() && des1.cols == 32, "Feature2D sizes");
+    int badkp = 0;
+    for (size_t i = 0; i < k.size() && i < kp1.size(); i++) {
+      const float deg = a[i] * 57.29577951308232f;
+      const bool ok = kp1[i].pt.x == (float)k[i].x && kp1[i].pt.y == (float)k[i].y && kp1[i].octave == lv[i] &&
+                      kp1[i].response == r[i] && kp1[i].angle >= 0.f && kp1[i].angle < 360.f &&
+                      std::fabs(std::fmod(kp1[i].angle - deg + 720.f, 360.f)) < 1e-3f &&
+                      std::fabs(kp1[i].size - 31.f * std::pow(1.2f, (float)lv[i])) < 1e-3f &&
+                      std::memcmp(des1.ptr((int)i), d[i].data, 32) == 0;
+      if (!ok) badkp++;
+    }
+    EXPECT(badkp == 0, "%d Feature2D keypoints differ from ORB::detectAndCompute", badkp);
+    orb->detect(image, kd);
+    EXPECT(kd.size() == kp1.size() && (kd.empty() || kd[0].angle == -1.f), "Feature2D::detect");
+    std::vector<orbx::Point2f> p0;
+    orbx::KeyPoint::convert(kd, p0);
+    EXPECT(p0.size() == kd.size() && (p0.empty() || (p0[0].x == kd[0].pt.x && p0[0].y == kd[0].pt.y)), "convert");
+    HammingMatcher matcher;
+    std::vector<orbx::Point2f> pts1, pts2;
+    orbx::get_matches(*orb, matcher, kp1, des1, orbx::Image(px2.data(), w, h), kp2, des2, pts1, pts2);
+    // the second frame is the first one moved by (-3, -2): matched level-0 points must agree with that
+    int consistent = 0;
+    for (size_t i = 0; i < pts1.size(); i++)
+      if (std::fabs(pts1[i].x - pts2[i].x - 3.f) <= 4.f && std::fabs(pts1[i].y - pts2[i].y - 2.f) <= 4.f) consistent++;
+    std::vector<DMatch> rm = matcher.ratioMatch(des1.d, des2.d, 0.8);
+    EXPECT(pts1.size() == rm.size() && pts1.size() == pts2.size() && pts1.size() > 100, "get_matches: %zu vs %zu",
+           pts1.size(), rm.size());
+    EXPECT(consistent * 10 >= (int)pts1.size() * 9, "only %d of %zu matches follow the shift", consistent, pts1.size());
+    std::printf("Feature2D/get_matches: %zu keypoints, %zu matches, %d consistent with the shift\n", kp1.size(),
+                pts1.size(), consistent);
   }
   std::printf(fails ? "FAILED (%d)\n" : "OK\n", fails);
   return fails ? 1 : 0;

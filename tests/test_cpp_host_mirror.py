@@ -19,7 +19,8 @@ def test_cpp_mirror_builds():
     for name in ("class ORB ", "class OrientedFAST ", "class RotatedBRIEF ", "class ORBCPU ", "inline int Fast(",
                  "inline void NMS(", "inline void HarrisScore(", "inline void Brief(", "inline void conv2d(",
                  "inline void GaussianBlur(", "inline void GaussianBlur1D(", "inline void GaussianBlurCUDA(",
-                 "inline void SobelCUDA(", "inline void Orientations("):
+                 "inline void SobelCUDA(", "inline void Orientations(", "class HammingMatcher ", "class Feature2D ",
+                 "struct KeyPoint ", "inline void get_matches("):
         assert name in hdr, name
 
 
@@ -34,4 +35,5 @@ def test_cpp_mirror_against_oracle(tmp_path):
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ORBCPU: 1178 keypoints, 0 not found, max Hamming 0" in r.stdout
+    assert "Feature2D/get_matches:" in r.stdout
     assert "OK" in r.stdout

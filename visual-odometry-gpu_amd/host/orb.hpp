@@ -32,10 +32,13 @@
 //     Fast.cu:8-18) and constructors print nothing;
 //   * HarrisScore takes `float k` (the reference's `int k` truncates 0.04 to 0, D7).
 #pragma once
+#include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/orbx.h"
@@ -423,3 +426,144 @@ class HammingMatcher {
  private:
   std::shared_ptr<orbx::detail::Ctx> ctx_;
 };
+
+// ---- cv::Feature2D-shaped adapter (next row) ---------------
+// What the VO executables hold is a `cv::Ptr<cv::Feature2D>` (`cv::ORB::create(3000)`,
+// src/feature_tracking.cpp:31) on which they call `detectAndCompute(img, cv::noArray(),
+// kp, des)` (src/feature_matching.cpp:164, src/feature_tracking.cpp:201) and `detect(img,
+// kp)` (src/feature_tracking.cpp:61), and of whose results they read `kp.pt` and an
+// N x 32 CV_8U descriptor matrix (src/feature_matching.cpp:179-180).  orbx::Feature2D gives
+// this front-end that call shape; orbx::KeyPoint carries the cv::KeyPoint fields with the
+// conventions cv::ORB uses for them (size = patch size x level scale, angle in degrees in
+// [0, 360), response = Harris response, octave = pyramid level).  With -DORBX_WITH_OPENCV
+// the cv::KeyPoint / cv::Mat overloads make it a literal replacement.
+namespace orbx {
+
+struct Point2f {  // cv::Point2f
+  float x = 0.f, y = 0.f;
+};
+
+struct KeyPoint {  // cv::KeyPoint
+  Point2f pt;
+  float size = 0.f;
+  float angle = -1.f;  // degrees, [0, 360); -1 = not computed (detect())
+  float response = 0.f;
+  int octave = 0;
+  int class_id = -1;
+  // cv::KeyPoint::convert(kp1, pts1), src/feature_tracking.cpp:62
+  static void convert(const std::vector<KeyPoint>& keypoints, std::vector<Point2f>& points2f) {
+    points2f.resize(keypoints.size());
+    for (size_t i = 0; i < keypoints.size(); i++) points2f[i] = keypoints[i].pt;
+  }
+};
+
+// N x 32 CV_8U descriptor matrix (row i = descriptor of keypoint i)
+struct DescriptorMat {
+  int rows = 0;
+  static constexpr int cols = 32;
+  std::vector<ORBDescriptor> d;
+  const uint8_t* ptr(int r) const { return d[(size_t)r].data; }
+  const uint8_t* data() const { return d.empty() ? nullptr : d[0].data; }  // rows x 32 contiguous bytes
+  bool empty() const { return rows == 0; }
+};
+
+inline float angle_degrees(float radians) {  // atan2f's (-pi, pi] -> cv::KeyPoint's [0, 360)
+  float a = radians * 57.29577951308232f;
+  if (a < 0.f) a += 360.f;
+  if (a >= 360.f) a -= 360.f;
+  return a;
+}
+
+class Feature2D {
+ public:
+  // cv::ORB::create(nfeatures, scaleFactor, nlevels), src/feature_tracking.cpp:31
+  static std::shared_ptr<Feature2D> create(int nfeatures = 500, float scaleFactor = 1.2f, int nlevels = 8) {
+    return std::shared_ptr<Feature2D>(new Feature2D(::ORB(nfeatures, scaleFactor, nlevels)));
+  }
+  static std::shared_ptr<Feature2D> create(const orbx_params& p) {
+    return std::shared_ptr<Feature2D>(new Feature2D(::ORB(p)));
+  }
+  // orb->detectAndCompute(img, cv::noArray(), kp, des); a mask is not supported (the
+  // reference never passes one)
+  void detectAndCompute(const Image& image, std::vector<KeyPoint>& keypoints, DescriptorMat& descriptors) {
+    run(image, keypoints, &descriptors);
+  }
+  // orb->detect(img, kp)
+  void detect(const Image& image, std::vector<KeyPoint>& keypoints) { run(image, keypoints, nullptr); }
+  int descriptorSize() const { return 32; }
+  const orbx_params& params() const { return orb_.params(); }
+
+#ifdef ORBX_WITH_OPENCV
+  void detectAndCompute(const cv::Mat& image, cv::InputArray /*mask = cv::noArray()*/,
+                        std::vector<cv::KeyPoint>& keypoints, cv::Mat& descriptors) {
+    std::vector<KeyPoint> k;
+    DescriptorMat d;
+    run(Image(image), k, &d);
+    to_cv(k, keypoints);
+    descriptors.create((int)k.size(), 32, CV_8U);
+    if (!k.empty()) std::memcpy(descriptors.data, d.data(), k.size() * 32);
+  }
+  void detect(const cv::Mat& image, std::vector<cv::KeyPoint>& keypoints) {
+    std::vector<KeyPoint> k;
+    run(Image(image), k, nullptr);
+    to_cv(k, keypoints);
+  }
+#endif
+
+ private:
+  explicit Feature2D(::ORB orb) : orb_(std::move(orb)) {}
+  void run(const Image& image, std::vector<KeyPoint>& keypoints, DescriptorMat* descriptors) {
+    orb_.detectAndCompute(image, kps_, angles_, desc_, &resp_, &levels_);
+    const orbx_params& p = orb_.params();
+    keypoints.resize(kps_.size());
+    for (size_t i = 0; i < kps_.size(); i++) {
+      KeyPoint& k = keypoints[i];
+      k.pt.x = (float)kps_[i].x;
+      k.pt.y = (float)kps_[i].y;
+      k.octave = levels_[i];
+      k.size = (float)p.patch_size * (float)std::pow((double)p.scale_factor, (double)levels_[i]);
+      k.angle = descriptors ? angle_degrees(angles_[i]) : -1.f;
+      k.response = resp_[i];
+      k.class_id = -1;
+    }
+    if (descriptors) {
+      descriptors->rows = (int)desc_.size();
+      descriptors->d = desc_;
+    }
+  }
+#ifdef ORBX_WITH_OPENCV
+  static void to_cv(const std::vector<KeyPoint>& k, std::vector<cv::KeyPoint>& out) {
+    out.resize(k.size());
+    for (size_t i = 0; i < k.size(); i++)
+      out[i] = cv::KeyPoint(k[i].pt.x, k[i].pt.y, k[i].size, k[i].angle, k[i].response, k[i].octave, k[i].class_id);
+  }
+#endif
+  ::ORB orb_;
+  std::vector<Keypoint> kps_;
+  std::vector<float> angles_, resp_;
+  std::vector<ORBDescriptor> desc_;
+  std::vector<int32_t> levels_;
+};
+
+// VisualOdom::get_matches (src/feature_matching.cpp:155-183): detect + describe frame 2,
+// 2-NN match frame 1 -> 2, keep `m.distance < 0.8 * n.distance`, return the matched points.
+inline void get_matches(Feature2D& orb, HammingMatcher& matcher, const std::vector<KeyPoint>& kp1,
+                        const DescriptorMat& des1, const Image& img2, std::vector<KeyPoint>& kp2, DescriptorMat& des2,
+                        std::vector<Point2f>& pts1, std::vector<Point2f>& pts2) {
+  orb.detectAndCompute(img2, kp2, des2);
+  std::vector<std::vector<DMatch>> matches;
+  matcher.knnMatch(des1.d, des2.d, matches, 2);
+  pts1.clear();
+  pts2.clear();
+  for (size_t i = 0; i < matches.size(); i++) {
+    if (matches[i].size() < 2) continue;
+    const DMatch& m = matches[i][0];
+    const DMatch& n = matches[i][1];
+    if (m.distance < 0.8 * n.distance) {
+      pts1.push_back(kp1[(size_t)m.queryIdx].pt);
+      pts2.push_back(kp2[(size_t)m.trainIdx].pt);
+    }
+  }
+}
+
+}  // namespace orbx
