@@ -280,6 +280,25 @@ int orbx_batch_match_consecutive(orbx_ctx* ctx, double ratio);
 int orbx_batch_match_fetch(orbx_ctx* ctx, int pair, int32_t* query_idx, int32_t* train_idx, int32_t* dist1,
                            int capacity, int* count);
 
+/* ---- next row: pyramidal Lucas-Kanade tracking ---------
+ * Replaces
+ *   cv::calcOpticalFlowPyrLK(img1, img2, pts1, pts2, status, err, cv::Size(21,21), 3,
+ *       cv::TermCriteria(COUNT + EPS, 30, 0.01))            src/feature_tracking.cpp:175-181
+ * (flags = 0, minEigThreshold = 1e-4: the defaults the reference leaves in place).
+ * prev / next: 8-bit gray images of the same size.  prev == NULL: the `next` image of
+ * the previous call on this context is this call's `prev` (the reference's
+ * `img1 = img2.clone()`, src/feature_tracking.cpp:112; its pyramid is still on the
+ * device).  prev_pts_xy / next_pts_xy: n (x, y) float pairs; status: n bytes (1 =
+ * tracked); err (optional): n floats, mean absolute window difference at level 0.
+ * OpenCV is absent from the image this library was written in: the arithmetic
+ * restates OpenCV 4.x's published algorithm (parity unpinned). */
+int orbx_lk_track(orbx_ctx* ctx, const uint8_t* prev, int prev_stride, const uint8_t* next, int next_stride,
+                  int width, int height, const float* prev_pts_xy, int n, float* next_pts_xy, uint8_t* status,
+                  float* err, int win_size, int max_level, int max_iters, double epsilon);
+/* number of pyramid levels calcOpticalFlowPyrLK would use for this geometry
+ * (max_level + 1 unless a level would not be larger than the window); -1 on bad arguments */
+int orbx_lk_pyramid_levels(int width, int height, int win_size, int max_level);
+
 #ifdef __cplusplus
 }
 #endif

@@ -184,6 +184,24 @@ void oracle_knn2(const uint8_t* query, int nq, const uint8_t* train, int nt, int
 int oracle_match_ratio(const uint8_t* query, int nq, const uint8_t* train, int nt, double ratio,
                        int32_t* query_idx, int32_t* train_idx, int32_t* dist1);
 
+/* ---- next row: pyramidal Lucas-Kanade tracking ---- */
+/* (lk_oracle.c; PARITY UNPINNED -- restates OpenCV 4.x's calcOpticalFlowPyrLK as
+ * called at feature_tracking.cpp:175-181, see the header of lk_oracle.c) */
+
+/* cv::pyrDown for 8UC1: 5x5 [1 4 6 4 1]^2, (sum + 128) >> 8, BORDER_REFLECT_101;
+ * dst is ((sw+1)/2) x ((sh+1)/2), tight. */
+void oracle_lk_pyr_down(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst);
+/* Scharr derivatives (dx, dy) as interleaved int16, REFLECT_101 (calcSharrDeriv) */
+void oracle_lk_scharr(const uint8_t* img, int w, int h, int stride, int16_t* deriv);
+/* calcOpticalFlowPyrLK(prev, next, prev_pts, next_pts, status, err, Size(win,win),
+ * max_level, TermCriteria(COUNT+EPS, max_iters, epsilon)), flags = 0,
+ * minEigThreshold = 1e-4.  prev_pts / next_pts: n (x, y) float pairs; err may be
+ * NULL.  Returns the top pyramid level actually used (<= max_level), -1 on bad
+ * arguments. */
+int oracle_lk_track(const uint8_t* prev, const uint8_t* next, int w, int h, int stride_prev, int stride_next,
+                    const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err, int win,
+                    int max_level, int max_iters, double epsilon);
+
 #ifdef __cplusplus
 }
 #endif

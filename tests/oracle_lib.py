@@ -41,7 +41,8 @@ def lib():
     if _LIB is None:
         so = os.path.join(ROOT, "oracle", "liborb_oracle.so")
         src = os.path.join(ROOT, "oracle", "orb_oracle.c")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        srcs = [src, os.path.join(ROOT, "oracle", "lk_oracle.c"), os.path.join(ROOT, "oracle", "orb_oracle.h")]
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in srcs):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
         _LIB = C.CDLL(so)
         _LIB.oracle_level_scale.restype = C.c_float
@@ -262,3 +263,37 @@ def match_ratio(query, train, ratio=0.8):
     f.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_double, i32p, i32p, i32p]
     m = f(_p(query, u8p), len(query), _p(train, u8p), len(train), ratio, _p(qi, i32p), _p(ti, i32p), _p(d1, i32p))
     return qi[:m].copy(), ti[:m].copy(), d1[:m].copy()
+
+
+def lk_pyr_down(img):
+    img, ip = _u8(img)
+    h, w = img.shape
+    out = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    lib().oracle_lk_pyr_down(ip, w, h, w, _p(out, u8p))
+    return out
+
+
+def lk_scharr(img):
+    img, ip = _u8(img)
+    h, w = img.shape
+    out = np.empty((h, w, 2), np.int16)
+    lib().oracle_lk_scharr(ip, w, h, w, out.ctypes.data_as(C.POINTER(C.c_int16)))
+    return out
+
+
+def lk_track(prev, nxt, pts, win=21, max_level=3, max_iters=30, epsilon=0.01):
+    """cv::calcOpticalFlowPyrLK(prev, next, pts, ...) (feature_tracking.cpp:175-181). Returns next_pts, status, err, top."""
+    prev, pp = _u8(prev)
+    nxt, np_ = _u8(nxt)
+    h, w = prev.shape
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    n = len(pts)
+    out = np.zeros((max(n, 1), 2), np.float32)
+    st = np.zeros(max(n, 1), np.uint8)
+    err = np.zeros(max(n, 1), np.float32)
+    f = lib().oracle_lk_track
+    f.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p, u8p, f32p, C.c_int, C.c_int,
+                  C.c_int, C.c_double]
+    top = f(pp, np_, w, h, w, w, _p(pts, f32p), n, _p(out, f32p), _p(st, u8p), _p(err, f32p), win, max_level,
+            max_iters, epsilon)
+    return out[:n].copy(), st[:n].copy(), err[:n].copy(), top

@@ -104,6 +104,10 @@ struct orbx_ctx {
   // stage-API scratch (grown on demand; never touched by the batched path)
   DevBuf s_img_a, s_img_b, s_f32, s_u16, s_mask, s_kps, s_f32b, s_desc, s_i32, s_kern;
   DevBuf m_q, m_t, m_idx, m_dist, m_match, m_cnt;  // matcher (stage API and batch)
+  // Lucas-Kanade tracker: two image pyramids (ping-pong: the `next` of one call is the
+  // `prev` of the following one), the derivative pyramid of the current `prev`, point buffers
+  DevBuf lk_img[2], lk_deriv, lk_pts, lk_out, lk_st, lk_err;
+  int lk_w = 0, lk_h = 0, lk_top = -1, lk_win = 0, lk_last = -1;  // lk_last: buffer holding the last `next`
   int match_pairs = 0;
 
   int timing = 0;  // 0 off, 1 all stages, 2 blur + fast only
@@ -684,7 +688,8 @@ void orbx_destroy(orbx_ctx* c) {
     if (b) (void)hipFree(b);
   if (c->h_out) (void)hipHostFree(c->h_out);
   DevBuf* sb[] = {&c->s_img_a, &c->s_img_b, &c->s_f32,  &c->s_u16, &c->s_mask, &c->s_kps,   &c->s_f32b, &c->s_desc,
-                  &c->s_i32,   &c->s_kern,  &c->s_tiles, &c->m_q,    &c->m_t,   &c->m_idx,  &c->m_dist,  &c->m_match, &c->m_cnt};
+                  &c->s_i32,   &c->s_kern,  &c->s_tiles, &c->m_q,    &c->m_t,   &c->m_idx,  &c->m_dist,  &c->m_match, &c->m_cnt,
+                  &c->lk_img[0], &c->lk_img[1], &c->lk_deriv, &c->lk_pts, &c->lk_out, &c->lk_st, &c->lk_err};
   for (DevBuf* b : sb)
     if (b->p) (void)hipFree(b->p);
   for (auto& e : c->ev)
@@ -1411,6 +1416,128 @@ int orbx_batch_match_fetch(orbx_ctx* c, int pair, int32_t* query_idx, int32_t* t
                            hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   return compact_matches(c, vm.data(), vd.data(), nq, query_idx, train_idx, dist1, capacity, count);
+}
+
+}  // extern "C"
+
+// ---- pyramidal Lucas-Kanade tracking (src/feature_tracking.cpp:166-193) ------------------
+
+namespace {
+struct LkGeom {
+  int top = 0;
+  int w[ORBX_LK_MAX_LEVELS], h[ORBX_LK_MAX_LEVELS], pitch[ORBX_LK_MAX_LEVELS];
+  size_t img_off[ORBX_LK_MAX_LEVELS], der_off[ORBX_LK_MAX_LEVELS];
+  size_t img_bytes = 0, der_bytes = 0;
+};
+// buildOpticalFlowPyramid: halve ((w+1)/2) until a level would not be larger than the window
+LkGeom lk_geometry(int w, int h, int win, int max_level) {
+  LkGeom g;
+  for (int l = 0; l <= max_level; l++) {
+    const int lw = l == 0 ? w : (g.w[l - 1] + 1) / 2, lh = l == 0 ? h : (g.h[l - 1] + 1) / 2;
+    if (l > 0 && (lw <= win || lh <= win)) break;
+    g.w[l] = lw;
+    g.h[l] = lh;
+    g.pitch[l] = align_up(lw, 64);
+    g.img_off[l] = g.img_bytes;
+    g.img_bytes += align_up_sz((size_t)g.pitch[l] * lh, 256);
+    g.der_off[l] = g.der_bytes;
+    g.der_bytes += align_up_sz((size_t)lw * lh * 4, 256);
+    g.top = l;
+  }
+  return g;
+}
+OrbxLkPyr lk_pyr(const LkGeom& g, const uint8_t* img, const uint8_t* deriv) {
+  OrbxLkPyr P;
+  std::memset(&P, 0, sizeof(P));
+  P.top = g.top;
+  for (int l = 0; l <= g.top; l++) {
+    P.L[l].img = img + g.img_off[l];
+    P.L[l].deriv = deriv ? reinterpret_cast<const int16_t*>(deriv + g.der_off[l]) : nullptr;
+    P.L[l].w = g.w[l];
+    P.L[l].h = g.h[l];
+    P.L[l].pitch = g.pitch[l];
+  }
+  return P;
+}
+// host image -> level 0, then pyrDown level by level
+int lk_upload(orbx_ctx* c, const LkGeom& g, DevBuf& b, const uint8_t* img, int stride) {
+  int st = ensure(c, b, g.img_bytes + 256);
+  if (st != ORBX_OK) return st;
+  uint8_t* base = (uint8_t*)b.p;
+  HIPCHK(c, hipMemcpy2DAsync(base, g.pitch[0], img, stride, g.w[0], g.h[0], hipMemcpyHostToDevice, c->stream));
+  for (int l = 1; l <= g.top; l++)
+    HIPCHK(c, orbx_launch_lk_pyrdown(c->stream, base + g.img_off[l - 1], g.w[l - 1], g.h[l - 1], g.pitch[l - 1],
+                                     base + g.img_off[l], g.w[l], g.h[l], g.pitch[l]));
+  return ORBX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int orbx_lk_track(orbx_ctx* c, const uint8_t* prev, int prev_stride, const uint8_t* next, int next_stride, int width,
+                  int height, const float* prev_pts_xy, int n, float* next_pts_xy, uint8_t* status, float* err,
+                  int win_size, int max_level, int max_iters, double epsilon) {
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  if (!next || n < 0 || (n > 0 && (!prev_pts_xy || !next_pts_xy || !status)))
+    return fail(c, ORBX_ERR_INVALID_ARG, "next image / point arrays are NULL");
+  if (width < 1 || height < 1 || next_stride < width || (prev && prev_stride < width))
+    return fail(c, ORBX_ERR_INVALID_ARG, "bad image size or stride");
+  if (win_size < 3 || win_size > 31 || max_level < 0 || max_level >= ORBX_LK_MAX_LEVELS)
+    return fail(c, ORBX_ERR_INVALID_ARG, "win_size must be in [3, 31], max_level in [0, 7]");
+  // TermCriteria sanitising of calcOpticalFlowPyrLK
+  max_iters = std::min(std::max(max_iters, 0), 100);
+  epsilon = std::min(std::max(epsilon, 0.0), 10.0);
+  const LkGeom g = lk_geometry(width, height, win_size, max_level);
+  int st;
+  int ip;  // buffer holding the `prev` pyramid
+  if (prev) {
+    ip = c->lk_last == 0 ? 1 : 0;
+    if ((st = lk_upload(c, g, c->lk_img[ip], prev, prev_stride)) != ORBX_OK) return st;
+  } else {
+    // the previous call's `next` image is this call's `prev` (img1 = img2.clone(), feature_tracking.cpp:112)
+    if (c->lk_last < 0 || c->lk_w != width || c->lk_h != height || c->lk_top != g.top || c->lk_win != win_size)
+      return fail(c, ORBX_ERR_INVALID_ARG, "prev == NULL needs a previous orbx_lk_track call of the same geometry");
+    ip = c->lk_last;
+  }
+  const int in = 1 - ip;
+  c->lk_last = -1;  // invalid until this call has succeeded
+  if ((st = lk_upload(c, g, c->lk_img[in], next, next_stride)) != ORBX_OK) return st;
+  if ((st = ensure(c, c->lk_deriv, g.der_bytes + 256)) != ORBX_OK) return st;
+  const uint8_t* pimg = (const uint8_t*)c->lk_img[ip].p;
+  for (int l = 0; l <= g.top; l++)
+    HIPCHK(c, orbx_launch_lk_scharr(c->stream, pimg + g.img_off[l], g.w[l], g.h[l], g.pitch[l],
+                                    reinterpret_cast<int16_t*>((uint8_t*)c->lk_deriv.p + g.der_off[l])));
+  if (n > 0) {
+    if ((st = ensure(c, c->lk_pts, sizeof(float) * 2 * (size_t)n)) != ORBX_OK) return st;
+    if ((st = ensure(c, c->lk_out, sizeof(float) * 2 * (size_t)n)) != ORBX_OK) return st;
+    if ((st = ensure(c, c->lk_st, (size_t)n)) != ORBX_OK) return st;
+    if ((st = ensure(c, c->lk_err, sizeof(float) * (size_t)n)) != ORBX_OK) return st;
+    HIPCHK(c, hipMemcpyAsync(c->lk_pts.p, prev_pts_xy, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice,
+                             c->stream));
+    const OrbxLkPyr P = lk_pyr(g, pimg, (const uint8_t*)c->lk_deriv.p);
+    const OrbxLkPyr N = lk_pyr(g, (const uint8_t*)c->lk_img[in].p, nullptr);
+    HIPCHK(c, orbx_launch_lk_track(c->stream, P, N, n, (const float*)c->lk_pts.p, (float*)c->lk_out.p,
+                                   (uint8_t*)c->lk_st.p, (float*)c->lk_err.p, win_size, max_iters,
+                                   epsilon * epsilon));
+    HIPCHK(c, hipMemcpyAsync(next_pts_xy, c->lk_out.p, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipMemcpyAsync(status, c->lk_st.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (err)
+      HIPCHK(c, hipMemcpyAsync(err, c->lk_err.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->lk_w = width;
+  c->lk_h = height;
+  c->lk_top = g.top;
+  c->lk_win = win_size;
+  c->lk_last = in;
+  return ORBX_OK;
+}
+
+int orbx_lk_pyramid_levels(int width, int height, int win_size, int max_level) {
+  if (width < 1 || height < 1 || win_size < 3 || win_size > 31 || max_level < 0 || max_level >= ORBX_LK_MAX_LEVELS)
+    return -1;
+  return lk_geometry(width, height, win_size, max_level).top + 1;
 }
 
 }  // extern "C"

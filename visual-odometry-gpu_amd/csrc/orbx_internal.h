@@ -108,6 +108,25 @@ int orbx_blur2_rows_per_wave();  // 16 or 32; tile height of k_blur2 = 4x this
 
 #define ORBX_MAX_SELECT 4096  // largest per-level FAST cap the selection kernel holds in LDS (16 B per candidate)
 
+// ---- pyramidal Lucas-Kanade tracking (orbx_lk.hip) ---------------------------
+#define ORBX_LK_MAX_LEVELS 8
+struct OrbxLkLevel {
+  const uint8_t* img;    // w x h, row pitch `pitch`
+  const int16_t* deriv;  // Scharr (dx, dy) pairs, w x h tight; NULL in the `next` pyramid
+  int32_t w, h, pitch, pad;
+};
+struct OrbxLkPyr {
+  OrbxLkLevel L[ORBX_LK_MAX_LEVELS];
+  int32_t top;  // highest level present
+  int32_t pad;
+};
+hipError_t orbx_launch_lk_pyrdown(hipStream_t s, const uint8_t* d_src, int sw, int sh, int spitch, uint8_t* d_dst,
+                                  int dw, int dh, int dpitch);
+hipError_t orbx_launch_lk_scharr(hipStream_t s, const uint8_t* d_img, int w, int h, int pitch, int16_t* d_deriv);
+hipError_t orbx_launch_lk_track(hipStream_t s, const OrbxLkPyr& prev, const OrbxLkPyr& next, int n,
+                                const float* d_prev_pts, float* d_next_pts, uint8_t* d_status, float* d_err, int win,
+                                int max_iters, double eps2);
+
 // ---- launchers (orbx_kernels.hip) ------------------------------------------
 // All take the stream explicitly and never synchronise or allocate.
 // d_tiles: tiles of ONE frame for 256 x 16 tiles

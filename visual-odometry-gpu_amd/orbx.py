@@ -28,7 +28,7 @@ EXPORTS = [
     "orbx_last_error_string", "orbx_status_string", "orbx_version", "orbx_get_plan",
     "orbx_detect_and_compute", "orbx_detect_and_compute_batch_device", "orbx_detect_and_compute_batch_host",
     "orbx_wait", "orbx_batch_results_device", "orbx_batch_fetch", "orbx_enable_stage_timing",
-    "orbx_last_stage_times", "orbx_stage_times_history", "orbx_bench_stage", "orbx_set_fast_early_exit", "orbx_fast_tile_counts", "orbx_fast_score", "orbx_nms", "orbx_fast",
+    "orbx_last_stage_times", "orbx_stage_times_history", "orbx_bench_stage", "orbx_set_fast_early_exit", "orbx_fast_tile_counts", "orbx_lk_track", "orbx_lk_pyramid_levels", "orbx_fast_score", "orbx_nms", "orbx_fast",
     "orbx_orientations", "orbx_brief", "orbx_harris", "orbx_blur5_sep", "orbx_blur5_273", "orbx_conv2d",
     "orbx_gaussian_blur_conv", "orbx_gaussian_kernel", "orbx_sobel", "orbx_build_pyramid_level",
     "orbx_select_top", "orbx_knn2", "orbx_match_ratio", "orbx_batch_match_consecutive", "orbx_batch_match_fetch",
@@ -257,6 +257,27 @@ class Context:
 
     def set_fast_early_exit(self, on=True):
         self._chk(self._lib.orbx_set_fast_early_exit(self._h, 1 if on else 0))
+
+    def lk_track(self, prev, nxt, pts, win=21, max_level=3, max_iters=30, epsilon=0.01):
+        """cv::calcOpticalFlowPyrLK(prev, next, pts, ...) as called at feature_tracking.cpp:175-181.
+        prev=None: the previous call's `next` image is this call's `prev`.  Returns next_pts, status, err."""
+        nxt = _img(nxt)
+        h, w = nxt.shape
+        if prev is not None:
+            prev = _img(prev)
+            if prev.shape != nxt.shape:
+                raise ValueError("prev and next must have the same size")
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        n = len(pts)
+        out = np.zeros((max(n, 1), 2), np.float32)
+        st = np.zeros(max(n, 1), np.uint8)
+        err = np.zeros(max(n, 1), np.float32)
+        f = self._lib.orbx_lk_track
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]
+        self._chk(f(self._h, _ptr(prev), w, _ptr(nxt), w, w, h, _ptr(pts), n, _ptr(out), _ptr(st), _ptr(err), win,
+                    max_level, max_iters, epsilon))
+        return out[:n].copy(), st[:n].copy(), err[:n].copy()
 
     def fast_tile_counts(self):
         """(tiles that did the full FAST/NMS work, all tiles) of the last whole-path batch."""
