@@ -234,6 +234,24 @@ def main():
         match_ms = (time.perf_counter() - t3) / 5 * 1e3
         n_matches = len(ctx.batch_match_fetch(0, cap)[0])
 
+    # Lucas-Kanade tracking between consecutive frames, the reference's call shape
+    # (calcOpticalFlowPyrLK 21x21 / 3 levels / 30 it. / 0.01, feature_tracking.cpp:175-181): host frame in,
+    # tracked points out, synchronous; the previous frame's pyramid stays on the device (prev=None)
+    lk = None
+    if rank == 0 and not args.only_timed and B > 1:
+        kps0, _ = ctx.fast(frames[0], 20, 9, 3, 3000)
+        pts0 = kps0.astype(np.float32)
+        ctx.lk_track(frames[0], frames[1 % B], pts0)
+        nlk = 50
+        t4 = time.perf_counter()
+        tracked = 0
+        for i in range(nlk):
+            _, st_lk, _ = ctx.lk_track(None, frames[(i + 2) % B], pts0)
+            tracked += int(st_lk.sum())
+        lk_ms = (time.perf_counter() - t4) / nlk * 1e3
+        lk = {"ms_per_frame": lk_ms, "points": int(len(pts0)), "tracked_mean": tracked / nlk,
+              "what": "orbx_lk_track: next frame in (host), tracked points out, cached previous pyramid, synchronous"}
+
     # per-frame host-in / host-out call (orbx_detect_and_compute, the reference's own call shape:
     # H2D of the frame + the whole path + one D2H of the results + sync), BASELINE.json configs[1]
     single = None
@@ -301,6 +319,7 @@ def main():
             "stage_ms_per_step": stage_ms,
             "fps_with_d2h": world * B / dt_d2h,
             "single_frame_host_to_host": single,
+            "lk_track": lk,
             "match_consecutive": {"ms_per_batch": match_ms, "pairs": B - 1, "matches_pair0": n_matches,
                                   "what": "Hamming 2-NN + 0.8 ratio test, frame i -> i+1, device-resident"},
             "keypoints_per_step": n_kp, "desc_checksum": csum,

@@ -221,6 +221,44 @@ int main(int argc, char** argv) {
     std::printf("Feature2D/get_matches: %zu keypoints, %zu matches, %d consistent with the shift\n", kp1.size(),
                 pts1.size(), consistent);
   }
+  // ---- track_optical_flow() shape (feature_tracking.cpp:166-193) vs the LK oracle
+  {
+    std::vector<uint8_t> px2(px);
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) px2[(size_t)y * w + x] = px[(size_t)((y + 2) % h) * w + (x + 3) % w];
+    auto orb = orbx::Feature2D::create(600);
+    std::vector<orbx::KeyPoint> kp1;
+    orb->detect(image, kp1);
+    std::vector<orbx::Point2f> pts1, pts2;
+    orbx::KeyPoint::convert(kp1, pts1);
+    const std::vector<orbx::Point2f> pts0 = pts1;
+    std::vector<float> onext(2 * pts0.size()), oerr(pts0.size());
+    std::vector<uint8_t> ost(pts0.size());
+    oracle_lk_track(px.data(), px2.data(), w, h, w, w, reinterpret_cast<const float*>(pts0.data()), (int)pts0.size(),
+                    onext.data(), ost.data(), oerr.data(), 21, 3, 30, 0.01);
+    orbx::LKTracker lk;
+    const orbx::Image img2(px2.data(), w, h);
+    orbx::track_optical_flow(lk, &image, img2, pts1, pts2);
+    size_t k = 0;
+    int bad = 0, shift_ok = 0;
+    for (size_t i = 0; i < pts0.size(); i++) {
+      if (!ost[i]) continue;
+      if (k >= pts2.size() || std::memcmp(&pts2[k], &onext[2 * i], 8) != 0 || std::memcmp(&pts1[k], &pts0[i], 8) != 0)
+        bad++;
+      else if (std::fabs(pts1[k].x - pts2[k].x - 3.f) < 0.5f && std::fabs(pts1[k].y - pts2[k].y - 2.f) < 0.5f)
+        shift_ok++;
+      k++;
+    }
+    EXPECT(k == pts2.size() && bad == 0, "track_optical_flow: %zu tracks vs oracle %zu, %d differ", pts2.size(), k, bad);
+    EXPECT(shift_ok * 10 >= (int)k * 8, "only %d of %zu tracks follow the shift", shift_ok, k);
+    // second call with the cached pyramid (img1 = img2.clone()): track back to the first frame
+    std::vector<orbx::Point2f> back;
+    std::vector<orbx::Point2f> fwd = pts2;
+    orbx::track_optical_flow(lk, nullptr, image, fwd, back);
+    EXPECT(back.size() > pts2.size() / 2, "backward tracking lost too many points");
+    std::printf("LKTracker: %zu of %zu points tracked, %d consistent with the shift, %zu tracked back\n", pts2.size(),
+                pts0.size(), shift_ok, back.size());
+  }
   std::printf(fails ? "FAILED (%d)\n" : "OK\n", fails);
   return fails ? 1 : 0;
 }

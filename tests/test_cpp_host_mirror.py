@@ -20,7 +20,7 @@ def test_cpp_mirror_builds():
                  "inline void NMS(", "inline void HarrisScore(", "inline void Brief(", "inline void conv2d(",
                  "inline void GaussianBlur(", "inline void GaussianBlur1D(", "inline void GaussianBlurCUDA(",
                  "inline void SobelCUDA(", "inline void Orientations(", "class HammingMatcher ", "class Feature2D ",
-                 "struct KeyPoint ", "inline void get_matches("):
+                 "struct KeyPoint ", "inline void get_matches(", "class LKTracker ", "inline void track_optical_flow("):
         assert name in hdr, name
 
 
@@ -36,4 +36,5 @@ def test_cpp_mirror_against_oracle(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ORBCPU: 1178 keypoints, 0 not found, max Hamming 0" in r.stdout
     assert "Feature2D/get_matches:" in r.stdout
+    assert "LKTracker:" in r.stdout
     assert "OK" in r.stdout

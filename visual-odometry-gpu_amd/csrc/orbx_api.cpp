@@ -1437,7 +1437,7 @@ LkGeom lk_geometry(int w, int h, int win, int max_level) {
     if (l > 0 && (lw <= win || lh <= win)) break;
     g.w[l] = lw;
     g.h[l] = lh;
-    g.pitch[l] = align_up(lw, 64);
+    g.pitch[l] = lw;  // tight: a host image with stride == width goes up in ONE contiguous copy
     g.img_off[l] = g.img_bytes;
     g.img_bytes += align_up_sz((size_t)g.pitch[l] * lh, 256);
     g.der_off[l] = g.der_bytes;
@@ -1464,7 +1464,10 @@ int lk_upload(orbx_ctx* c, const LkGeom& g, DevBuf& b, const uint8_t* img, int s
   int st = ensure(c, b, g.img_bytes + 256);
   if (st != ORBX_OK) return st;
   uint8_t* base = (uint8_t*)b.p;
-  HIPCHK(c, hipMemcpy2DAsync(base, g.pitch[0], img, stride, g.w[0], g.h[0], hipMemcpyHostToDevice, c->stream));
+  if (stride == g.w[0])
+    HIPCHK(c, hipMemcpyAsync(base, img, (size_t)g.w[0] * g.h[0], hipMemcpyHostToDevice, c->stream));
+  else  // (row-by-row in the runtime: slow, but only for padded host images)
+    HIPCHK(c, hipMemcpy2DAsync(base, g.pitch[0], img, stride, g.w[0], g.h[0], hipMemcpyHostToDevice, c->stream));
   for (int l = 1; l <= g.top; l++)
     HIPCHK(c, orbx_launch_lk_pyrdown(c->stream, base + g.img_off[l - 1], g.w[l - 1], g.h[l - 1], g.pitch[l - 1],
                                      base + g.img_off[l], g.w[l], g.h[l], g.pitch[l]));

@@ -13,10 +13,11 @@
 //   k_lk_pyrdown  cv::pyrDown (5x5 [1 4 6 4 1]^2 / 256, REFLECT_101), thread per output pixel
 //   k_lk_scharr   Scharr (3,10,3) derivative pairs as int16, REFLECT_101, thread per pixel
 //   k_lk_track    ONE WAVEFRONT PER POINT walks the levels top -> 0.  The 21x21 template
-//                 (intensity + two gradients, int16) lives in the wave's LDS slice; every
-//                 Newton step samples the 441 window pixels of the next image (7 per lane,
-//                 4 byte loads each, L1/L2 resident), and reduces the two mismatch sums with
-//                 DPP.  All control flow is wave-uniform.
+//                 (intensity + two gradients, int16) and a 26x26 neighbourhood of the next
+//                 image live in the wave's LDS slice; every Newton step samples the 441
+//                 window pixels from LDS (7 per lane) and reduces the two mismatch sums with
+//                 DPP; the neighbourhood is re-fetched only when the window leaves it.  All
+//                 control flow is wave-uniform, there is no workgroup barrier.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -120,17 +121,69 @@ __device__ __forceinline__ short2 lk_deriv_at(const OrbxLkLevel& L, int X, int Y
 }
 
 #define LK_MAX_WIN 31
-#define LK_MAX_ITEMS ((LK_MAX_WIN * LK_MAX_WIN + 63) / 64)  // 16
+// The Newton steps of a level move the window by fractions of a pixel, so its integer
+// origin hardly ever changes: the (win + 1 + 2 * LK_JC_MARGIN)^2 neighbourhood of the next
+// image is cached in LDS (border reflection resolved while loading) and re-fetched only when
+// the window leaves it.  One global round trip per level instead of one per iteration.
+#define LK_JC_MARGIN 2
+#define LK_JC_MAX (LK_MAX_WIN + 1 + 2 * LK_JC_MARGIN)  // 36
+
+__device__ __forceinline__ void lk_wave_lds_sync() {
+  // LDS operations of one wave execute in order; this only pins the compiler
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct LkCache {
+  uint8_t* px;  // jce x jce bytes
+  int jce, x0, y0;
+  uint32_t rcp;
+  bool valid;
+};
+
+// makes sure the cache covers [inx, inx + win] x [iny, iny + win]
+__device__ __forceinline__ void lk_cache_cover(LkCache& c, const OrbxLkLevel& J, int inx, int iny, int win, int lane) {
+  if (c.valid && inx >= c.x0 && iny >= c.y0 && inx + win + 1 <= c.x0 + c.jce && iny + win + 1 <= c.y0 + c.jce) return;
+  lk_wave_lds_sync();  // earlier reads of the old contents are done
+  c.x0 = inx - LK_JC_MARGIN;
+  c.y0 = iny - LK_JC_MARGIN;
+  const bool interior = c.x0 >= 0 && c.y0 >= 0 && c.x0 + c.jce <= J.w && c.y0 + c.jce <= J.h;
+  for (int idx = lane; idx < c.jce * c.jce; idx += 64) {
+    const int y = (int)(((uint32_t)idx * c.rcp) >> 16), x = idx - y * c.jce;
+    int v;
+    if (interior)
+      v = J.img[(size_t)(c.y0 + y) * J.pitch + (c.x0 + x)];
+    else
+      v = J.img[(size_t)lk_reflect(c.y0 + y, J.h) * J.pitch + lk_reflect(c.x0 + x, J.w)];
+    c.px[idx] = (uint8_t)v;
+  }
+  c.valid = true;
+  lk_wave_lds_sync();
+}
+
+// bilinear sample of the cached next image at window position (x, y) of origin (inx, iny)
+__device__ __forceinline__ int lk_sample_cached(const LkCache& c, int inx, int iny, int x, int y, const LkWeights& w) {
+  const uint8_t* p = c.px + (iny - c.y0 + y) * c.jce + (inx - c.x0 + x);
+  return lk_descale(p[0] * w.w00 + p[1] * w.w01 + p[c.jce] * w.w10 + p[c.jce + 1] * w.w11, 14 - 5);
+}
 
 __global__ __launch_bounds__(256) void k_lk_track(OrbxLkPyr P, OrbxLkPyr N, int n, const float2* __restrict__ prev_pts,
                                                   float2* __restrict__ next_pts, uint8_t* __restrict__ status,
                                                   float* __restrict__ err, int win, int max_iters, double eps2) {
   // per wave: the template, (intensity, dx, dy) as int16 (4th lane of the short4 unused)
   __shared__ short4 s_tpl[4][LK_MAX_WIN * LK_MAX_WIN];
+  __shared__ uint8_t s_jc[4][LK_JC_MAX * LK_JC_MAX];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
   if (i >= n) return;  // whole wave
   short4* tpl = s_tpl[wave];
+  LkCache jc;
+  jc.px = s_jc[wave];
+  jc.jce = win + 1 + 2 * LK_JC_MARGIN;
+  jc.rcp = (65536u + (uint32_t)jc.jce - 1u) / (uint32_t)jc.jce;  // idx / jce for idx < 36^2
+  jc.x0 = jc.y0 = 0;
+  jc.valid = false;
   const int nitem = win * win;
   const uint32_t rcp = (65536u + (uint32_t)win - 1u) / (uint32_t)win;  // idx / win == (idx * rcp) >> 16 for idx < 961
   const float half = (float)(win - 1) * 0.5f;
@@ -145,6 +198,7 @@ __global__ __launch_bounds__(256) void k_lk_track(OrbxLkPyr P, OrbxLkPyr N, int 
   for (int level = P.top; level >= 0; level--) {
     const OrbxLkLevel& I = P.L[level];
     const OrbxLkLevel& J = N.L[level];
+    jc.valid = false;
     const float sc = (float)(1.0 / (double)(1 << level));
     float px = __fmul_rn(pp.x, sc), py = __fmul_rn(pp.y, sc);
     float nx, ny;
@@ -205,12 +259,12 @@ __global__ __launch_bounds__(256) void k_lk_track(OrbxLkPyr P, OrbxLkPyr N, int 
         break;
       }
       const LkWeights wj = lk_weights(nx - (float)inx, ny - (float)iny);
-      const bool in_j = inx >= 0 && iny >= 0 && inx + win + 1 <= J.w && iny + win + 1 <= J.h;
+      lk_cache_cover(jc, J, inx, iny, win, lane);
       int b1 = 0, b2 = 0;
       for (int idx = lane; idx < nitem; idx += 64) {
         const int y = (int)(((uint32_t)idx * rcp) >> 16), x = idx - y * win;
         const short4 t = tpl[idx];
-        const int diff = lk_sample(J, inx + x, iny + y, wj, in_j) - t.x;
+        const int diff = lk_sample_cached(jc, inx, iny, x, y, wj) - t.x;
         b1 += diff * t.y;
         b2 += diff * t.z;
       }
@@ -238,11 +292,11 @@ __global__ __launch_bounds__(256) void k_lk_track(OrbxLkPyr P, OrbxLkPyr N, int 
         continue;
       }
       const LkWeights wj = lk_weights(ex - (float)inx, ey - (float)iny);
-      const bool in_j = inx >= 0 && iny >= 0 && inx + win + 1 <= J.w && iny + win + 1 <= J.h;
+      lk_cache_cover(jc, J, inx, iny, win, lane);
       int e = 0;
       for (int idx = lane; idx < nitem; idx += 64) {
         const int y = (int)(((uint32_t)idx * rcp) >> 16), x = idx - y * win;
-        const int diff = lk_sample(J, inx + x, iny + y, wj, in_j) - tpl[idx].x;
+        const int diff = lk_sample_cached(jc, inx, iny, x, y, wj) - tpl[idx].x;
         e += diff < 0 ? -diff : diff;
       }
       ev = __fmul_rn(lk_exact_sum_f32(e), __fdiv_rn(1.f, (float)(32 * win * win)));

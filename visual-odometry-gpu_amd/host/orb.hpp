@@ -566,4 +566,65 @@ inline void get_matches(Feature2D& orb, HammingMatcher& matcher, const std::vect
   }
 }
 
+// ---- pyramidal Lucas-Kanade tracking (next row) ---------------
+// cv::calcOpticalFlowPyrLK(img1, img2, pts1, pts2, status, err, cv::Size(21,21), 3,
+//     cv::TermCriteria(COUNT + EPS, 30, 0.01))                 src/feature_tracking.cpp:175-181
+struct Size {  // cv::Size
+  int width = 21, height = 21;
+  Size() = default;
+  Size(int w, int h) : width(w), height(h) {}
+};
+struct TermCriteria {  // cv::TermCriteria(COUNT + EPS, maxCount, epsilon)
+  int maxCount = 30;
+  double epsilon = 0.01;
+  TermCriteria() = default;
+  TermCriteria(int count, double eps) : maxCount(count), epsilon(eps) {}
+};
+
+class LKTracker {
+ public:
+  LKTracker() : ctx_(detail::stage_ctx()) {}
+  // prevImg == nullptr: the previous call's nextImg is this call's prevImg (its pyramid is still on the
+  // device): the `img1 = img2.clone()` of the reference's loop, src/feature_tracking.cpp:112
+  void calcOpticalFlowPyrLK(const Image* prevImg, const Image& nextImg, const std::vector<Point2f>& prevPts,
+                            std::vector<Point2f>& nextPts, std::vector<uint8_t>& status, std::vector<float>& err,
+                            Size winSize = Size(21, 21), int maxLevel = 3, TermCriteria criteria = TermCriteria()) {
+    if (winSize.width != winSize.height) throw std::runtime_error("calcOpticalFlowPyrLK: square windows only");
+    if (prevImg && (prevImg->width != nextImg.width || prevImg->height != nextImg.height))
+      throw std::runtime_error("calcOpticalFlowPyrLK: image sizes differ");
+    orbx_ctx* c = ctx_->get(8, 8);
+    const int n = (int)prevPts.size();
+    nextPts.resize(prevPts.size());
+    status.resize(prevPts.size());
+    err.resize(prevPts.size());
+    detail::check(c,
+                  orbx_lk_track(c, prevImg ? prevImg->data : nullptr, prevImg ? prevImg->stride : 0, nextImg.data,
+                                nextImg.stride, nextImg.width, nextImg.height,
+                                reinterpret_cast<const float*>(prevPts.data()), n,
+                                reinterpret_cast<float*>(nextPts.data()), status.data(), err.data(), winSize.width,
+                                maxLevel, criteria.maxCount, criteria.epsilon),
+                  "calcOpticalFlowPyrLK");
+  }
+
+ private:
+  std::shared_ptr<detail::Ctx> ctx_;
+};
+
+// VisualOdom::track_optical_flow (src/feature_tracking.cpp:166-193): track pts1 into img2, drop lost tracks
+inline void track_optical_flow(LKTracker& lk, const Image* img1, const Image& img2, std::vector<Point2f>& pts1,
+                               std::vector<Point2f>& pts2) {
+  if (pts1.empty()) return;
+  std::vector<uint8_t> status;
+  std::vector<float> err;
+  lk.calcOpticalFlowPyrLK(img1, img2, pts1, pts2, status, err, Size(21, 21), 3, TermCriteria(30, 0.01));
+  std::vector<Point2f> v1, v2;
+  for (size_t i = 0; i < status.size(); i++)
+    if (status[i]) {
+      v1.push_back(pts1[i]);
+      v2.push_back(pts2[i]);
+    }
+  pts1 = v1;
+  pts2 = v2;
+}
+
 }  // namespace orbx
