@@ -101,7 +101,9 @@ struct __attribute__((packed, aligned(1))) uint2_unaligned {
   uint32_t x, y;
   __device__ operator uint2() const { return make_uint2(x, y); }
 };
-#define PYR2_ROWS 4  // output rows per wave
+#define PYR2_ROWS 4    // output rows per group
+#define PYR2_GROUPS 1  // groups per wave (2 measured slower: 70 vs 65 us)
+static_assert(ORBX_PYR2_TH == 4 * PYR2_ROWS * PYR2_GROUPS, "tile height = 4 waves x groups x rows");
 
 __global__ __launch_bounds__(256) void k_pyramid2(const OrbxTileDesc* __restrict__ tiles, int frame_bytes, int w0,
                                                   int h0, const uint8_t* __restrict__ in, int in_stride,
@@ -120,8 +122,8 @@ __global__ __launch_bounds__(256) void k_pyramid2(const OrbxTileDesc* __restrict
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint8_t* src = in + (size_t)f * in_frame_stride;
   const int x = tx * 256 + lane * 4;
-  const int yb = ty * (4 * PYR2_ROWS) + wave * PYR2_ROWS;
-  if (yb >= L.h) return;  // whole wave
+  const int yb0 = ty * ORBX_PYR2_TH + wave * (PYR2_ROWS * PYR2_GROUPS);
+  if (yb0 >= L.h) return;  // whole wave
   const int pitch = L.pitch, w = L.w;
   const __amdgpu_buffer_rsrc_t rout =
       __builtin_amdgcn_make_buffer_rsrc(pyr + (size_t)f * frame_bytes + d.img_off, 0, pitch * L.h, 0x00020000);
@@ -131,17 +133,19 @@ __global__ __launch_bounds__(256) void k_pyramid2(const OrbxTileDesc* __restrict
 
   if (l == 0) {  // level 0 = the input frame (src/orb.cpp:112), re-pitched
 #pragma unroll
-    for (int r = 0; r < PYR2_ROWS; r++) {
-      const int y = yb + r;
+    for (int r = 0; r < PYR2_ROWS * PYR2_GROUPS; r++) {
+      const int y = yb0 + r;
       if (y < L.h) {
         const uint8_t* row = src + (size_t)y * in_stride;
         uint32_t v = 0;
-        if (nvalid >= 4) {
+        if (nvalid >= 4 || (nvalid > 0 && y + 1 < L.h)) {
+          // (a partial last dword of a row above the last one runs into the next row of the
+          // same frame: readable, and vmask drops those bytes)
           v = *reinterpret_cast<const u32_unaligned*>(row + x);
-        } else if (nvalid > 0) {  // last dword of the row: never read past it
+        } else if (nvalid > 0) {  // last dword of the last row: never read past the frame
           for (int k = 0; k < nvalid; k++) v |= (uint32_t)row[x + k] << (8 * k);
         }
-        __builtin_amdgcn_raw_buffer_store_b32(v, rout, voff_st, y * pitch, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(v & vmask, rout, voff_st, y * pitch, 0);
       }
     }
     return;
@@ -155,6 +159,13 @@ __global__ __launch_bounds__(256) void k_pyramid2(const OrbxTileDesc* __restrict
     ofs[0] = t01.x; ofs[1] = t01.z; ofs[2] = t23.x; ofs[3] = t23.z;
     cc[0] = t01.y; cc[1] = t01.w; cc[2] = t23.y; cc[3] = t23.w;
   }
+  // a wave serves PYR2_GROUPS groups of PYR2_ROWS rows one after the other: the tile descriptor
+  // and the x taps (two dependent memory round trips) are paid once per wave, the registers
+  // hold one group
+#pragma unroll 1
+  for (int g = 0; g < PYR2_GROUPS; g++) {
+  const int yb = yb0 + g * PYR2_ROWS;
+  if (yb >= L.h) break;
   // gather phase: 2 source rows x 4 pixel pairs x 4 output rows
   uint32_t p0[PYR2_ROWS][4], p1[PYR2_ROWS][4];
   int b0[PYR2_ROWS], b1[PYR2_ROWS];
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(256) void k_pyramid2(const OrbxTileDesc* __restrict
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const uint32_t sb = ofs[k] - base;  // 0..6
-      sel[k] = 0x0c0c0000u | ((sb + 1) << 8) | sb;
+      sel[k] = 0x0c000c00u | ((sb + 1) << 16) | sb;  // (src[ofs], src[ofs+1]) as two u16 lanes
     }
 #pragma unroll
     for (int r = 0; r < PYR2_ROWS; r++) {
@@ -198,29 +209,33 @@ __global__ __launch_bounds__(256) void k_pyramid2(const OrbxTileDesc* __restrict
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         // ofs <= w0-2 always (host table): one unaligned 16-bit load fetches src[ofs], src[ofs+1]
-        p0[r][k] = *reinterpret_cast<const u16_unaligned*>(S0 + ofs[k]);
-        p1[r][k] = *reinterpret_cast<const u16_unaligned*>(S1 + ofs[k]);
+        const uint32_t q0 = *reinterpret_cast<const u16_unaligned*>(S0 + ofs[k]);
+        const uint32_t q1 = *reinterpret_cast<const u16_unaligned*>(S1 + ofs[k]);
+        p0[r][k] = __builtin_amdgcn_perm(q0, q0, 0x0c010c00u);
+        p1[r][k] = __builtin_amdgcn_perm(q1, q1, 0x0c010c00u);
       }
     }
   }
-  int c0[4], c1[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    c0[k] = (int)(cc[k] & 0xffffu);
-    c1[k] = (int)(cc[k] >> 16);
-  }
+  // horizontal pass: src[ofs] * c0 + src[ofs+1] * c1 is one v_dot2_u32_u16 of the pixel pair
+  // (two u16 lanes) with the tap's packed (c0, c1)
 #pragma unroll
   for (int r = 0; r < PYR2_ROWS; r++) {
     uint32_t out = 0;
+    const uint32_t bs0 = ((uint32_t)b0[r] << 12) & 0xffffffu, bs1 = ((uint32_t)b1[r] << 12) & 0xffffffu;  // b <= 2048
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int r0 = (int)(p0[r][k] & 0xffu) * c0[k] + (int)(p0[r][k] >> 8) * c1[k];
-      const int r1 = (int)(p1[r][k] & 0xffu) * c0[k] + (int)(p1[r][k] >> 8) * c1[k];
-      const uint32_t v = (uint32_t)((((b0[r] * (r0 >> 4)) >> 16) + ((b1[r] * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
-      out |= v << (8 * k);
+      const us2_t cw = __builtin_bit_cast(us2_t, cc[k]);
+      const int r0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, p0[r][k]), cw, 0u, false);
+      const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, p1[r][k]), cw, 0u, false);
+      // (b * (r >> 4)) >> 16 == ((r & ~15) * (b << 12)) >> 32 with both factors below 2^24:
+      // one v_and + one full-rate v_mul_hi_u32_u24 per term; the sum is at most 1022, so no mask
+      const uint32_t t0 = (uint32_t)(((u64)((uint32_t)r0 & 0xfffff0u) * (u64)bs0) >> 32);
+      const uint32_t t1 = (uint32_t)(((u64)((uint32_t)r1 & 0xfffff0u) * (u64)bs1) >> 32);
+      out |= ((t0 + t1 + 2u) >> 2) << (8 * k);
     }
     const int y = yb + r;
     if (y < L.h) __builtin_amdgcn_raw_buffer_store_b32(out & vmask, rout, voff_st, y * pitch, 0);
+  }
   }
 }
 

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborbx.so")
+LIB_PATH = os.environ.get("ORBX_LIB") or os.path.join(_HERE, "liborbx.so")  # ORBX_LIB: A/B builds (diagnostics)
 
 MAX_LEVELS = 16
 OK, ERR_INVALID_ARG, ERR_CAPACITY, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED = range(6)
