@@ -358,6 +358,9 @@ __global__ __launch_bounds__(256) void k_blur(OrbxPlan plan, OrbxTileMap tm, con
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) + __builtin_bit_cast(us2_t, b)));
 }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) - __builtin_bit_cast(us2_t, b)));
+}
 __device__ __forceinline__ uint32_t pk_mad(uint32_t a, unsigned short m, uint32_t c) {
   const us2_t mm = {m, m};
   return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) * mm + __builtin_bit_cast(us2_t, c)));
@@ -1511,25 +1514,32 @@ __device__ __forceinline__ void desc_box_tables(DescLds& lds, int lane) {
   }
   wave_lds_sync();
   {
-    int r = lane / 10, g = lane - r * 10;
+    // vertical pass as running sums: lane (chunk, g) walks 6 (chunk 0: 7) consecutive rows of
+    // column group g, box[r+1] = box[r] + hs[r+5] - hs[r]; the five live hs rows stay in
+    // registers, so a row costs ONE 8-byte read and 4 packed ops instead of 5 reads and 8 ops
+    static_assert(DESC_BROWS == 37, "6 chunks: 7 + 5 x 6 rows");
+    const int chunk = lane / 10, g = lane - chunk * 10;
+    if (chunk < 6) {
+      const int r0 = chunk == 0 ? 0 : 6 * chunk + 1, nrows = chunk == 0 ? 7 : 6;
+      const uint2* hp = reinterpret_cast<const uint2*>(&lds.hs[r0 * DESC_HP + 4 * g]);
+      uint2* bp = reinterpret_cast<uint2*>(&lds.box[r0 * DESC_HP + 4 * g]);
+      uint2 q[5];
 #pragma unroll
-    for (int k = 0; k < (DESC_BROWS * 10 + 63) / 64; k++) {
-      if (lane + 64 * k < DESC_BROWS * 10) {
-        const uint2* hp = reinterpret_cast<const uint2*>(&lds.hs[r * DESC_HP + 4 * g]);
-        uint2 acc = hp[0];
+      for (int i = 0; i < 5; i++) q[i] = hp[i * (DESC_HP / 4)];
+      uint2 acc;
+      acc.x = pk_add(pk_add(pk_add(q[0].x, q[1].x), pk_add(q[2].x, q[3].x)), q[4].x);
+      acc.y = pk_add(pk_add(pk_add(q[0].y, q[1].y), pk_add(q[2].y, q[3].y)), q[4].y);
+      bp[0] = acc;
 #pragma unroll
-        for (int q = 1; q < 5; q++) {
-          const uint2 v = hp[q * (DESC_HP / 4)];
-          acc.x = pk_add(acc.x, v.x);
-          acc.y = pk_add(acc.y, v.y);
+      for (int i = 1; i < 7; i++) {
+        if (i < nrows) {
+          const uint2 nw = hp[(i + 4) * (DESC_HP / 4)];
+          const uint2 od = q[(i - 1) % 5];
+          acc.x = pk_sub(pk_add(acc.x, nw.x), od.x);
+          acc.y = pk_sub(pk_add(acc.y, nw.y), od.y);
+          q[(i - 1) % 5] = nw;
+          bp[i * (DESC_HP / 4)] = acc;
         }
-        *reinterpret_cast<uint2*>(&lds.box[r * DESC_HP + 4 * g]) = acc;
-      }
-      r += 6;
-      g += 4;
-      if (g >= 10) {
-        g -= 10;
-        r += 1;
       }
     }
   }
@@ -1551,7 +1561,7 @@ __device__ __forceinline__ f2_t lround_f2(f2_t v) {
   return t + __builtin_elementwise_trunc(fr + fr);
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_describe2(OrbxPlan plan, const uint8_t* __restrict__ pyr, int patch_size,
+__global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t* __restrict__ pyr, int patch_size,
                                                    const int32_t* __restrict__ sel_count,
                                                    const orbx_keypoint* __restrict__ sel_lkp,
                                                    const float* __restrict__ sel_resp,
