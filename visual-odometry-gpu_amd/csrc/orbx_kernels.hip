@@ -1495,51 +1495,40 @@ __device__ __forceinline__ DescJob desc_job(const OrbxPlan& plan, const uint8_t*
   return jb;
 }
 
-__device__ __forceinline__ void desc_box_tables(DescLds& lds, int lane) {
-  {
-    int r = lane / 10, g = lane - r * 10;
+// The 5x5 box-sum table of k_describe2, horizontal and vertical pass fused: lane (chunk, g)
+// walks 6 (chunk 0: 7) consecutive table rows of column group g (4 columns).  Per patch row it
+// reads 8 bytes and gets the four horizontal 5-sums with one v_qsad_pk_u16_u8; the vertical sum
+// is a running sum, box[r+1] = box[r] + hs[r+5] - hs[r], with the five live hs rows in
+// registers.  The table (37 x DESC_HP u16) is written over lds.hs; the patch stays intact.
+// LDS traffic per keypoint: 11 reads + 7 writes per lane instead of 32 accesses for two
+// separate passes through an intermediate hs array.
+__device__ __forceinline__ void desc_box_table_fused(DescLds& lds, int lane) {
+  static_assert(DESC_BROWS == 37, "6 chunks: 7 + 5 x 6 rows");
+  const int chunk = lane / 10, g = lane - chunk * 10;
+  if (chunk < 6) {
+    const int r0 = chunk == 0 ? 0 : 6 * chunk + 1, nrows = chunk == 0 ? 7 : 6;
+    const uint32_t* pp = &lds.patch[r0 * (DESC_PITCH / 4) + g];
+    uint2* bp = reinterpret_cast<uint2*>(&lds.hs[r0 * DESC_HP + 4 * g]);
+    auto hrow = [&](int i) {
+      const u64 v = hsum5x4(pp[i * (DESC_PITCH / 4)], pp[i * (DESC_PITCH / 4) + 1]);
+      return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+    };
+    uint2 q[5];
 #pragma unroll
-    for (int k = 0; k < (DESC_ROWS * 10 + 63) / 64; k++) {
-      if (lane + 64 * k < DESC_ROWS * 10) {
-        const uint32_t d0 = lds.patch[r * (DESC_PITCH / 4) + g], d1 = lds.patch[r * (DESC_PITCH / 4) + g + 1];
-        *reinterpret_cast<u64*>(&lds.hs[r * DESC_HP + 4 * g]) = hsum5x4(d0, d1);
-      }
-      r += 6;
-      g += 4;
-      if (g >= 10) {
-        g -= 10;
-        r += 1;
-      }
-    }
-  }
-  wave_lds_sync();
-  {
-    // vertical pass as running sums: lane (chunk, g) walks 6 (chunk 0: 7) consecutive rows of
-    // column group g, box[r+1] = box[r] + hs[r+5] - hs[r]; the five live hs rows stay in
-    // registers, so a row costs ONE 8-byte read and 4 packed ops instead of 5 reads and 8 ops
-    static_assert(DESC_BROWS == 37, "6 chunks: 7 + 5 x 6 rows");
-    const int chunk = lane / 10, g = lane - chunk * 10;
-    if (chunk < 6) {
-      const int r0 = chunk == 0 ? 0 : 6 * chunk + 1, nrows = chunk == 0 ? 7 : 6;
-      const uint2* hp = reinterpret_cast<const uint2*>(&lds.hs[r0 * DESC_HP + 4 * g]);
-      uint2* bp = reinterpret_cast<uint2*>(&lds.box[r0 * DESC_HP + 4 * g]);
-      uint2 q[5];
+    for (int i = 0; i < 5; i++) q[i] = hrow(i);
+    uint2 acc;
+    acc.x = pk_add(pk_add(pk_add(q[0].x, q[1].x), pk_add(q[2].x, q[3].x)), q[4].x);
+    acc.y = pk_add(pk_add(pk_add(q[0].y, q[1].y), pk_add(q[2].y, q[3].y)), q[4].y);
+    bp[0] = acc;
 #pragma unroll
-      for (int i = 0; i < 5; i++) q[i] = hp[i * (DESC_HP / 4)];
-      uint2 acc;
-      acc.x = pk_add(pk_add(pk_add(q[0].x, q[1].x), pk_add(q[2].x, q[3].x)), q[4].x);
-      acc.y = pk_add(pk_add(pk_add(q[0].y, q[1].y), pk_add(q[2].y, q[3].y)), q[4].y);
-      bp[0] = acc;
-#pragma unroll
-      for (int i = 1; i < 7; i++) {
-        if (i < nrows) {
-          const uint2 nw = hp[(i + 4) * (DESC_HP / 4)];
-          const uint2 od = q[(i - 1) % 5];
-          acc.x = pk_sub(pk_add(acc.x, nw.x), od.x);
-          acc.y = pk_sub(pk_add(acc.y, nw.y), od.y);
-          q[(i - 1) % 5] = nw;
-          bp[i * (DESC_HP / 4)] = acc;
-        }
+    for (int i = 1; i < 7; i++) {
+      if (i < nrows) {
+        const uint2 nw = hrow(i + 4);
+        const uint2 od = q[(i - 1) % 5];
+        acc.x = pk_sub(pk_add(acc.x, nw.x), od.x);
+        acc.y = pk_sub(pk_add(acc.y, nw.y), od.y);
+        q[(i - 1) % 5] = nw;
+        bp[i * (DESC_HP / 4)] = acc;
       }
     }
   }
@@ -1728,7 +1717,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
       const int q = wave * DESC_KPW + j, slot = slot0 + q, off = offs[j];
       desc_store_patch(lds, lane, regs[j]);
       wave_lds_sync();
-      desc_box_tables(lds, lane);
+      desc_box_table_fused(lds, lane);
       const float c = s_cs[q][0], s = s_cs[q][1];
       // every rotated centre is within 18 px of the keypoint; with a 20 px margin no test can be skipped
       const bool interior = jb.x >= DESC_R && jb.y >= DESC_R && jb.x < jb.w - DESC_R && jb.y < jb.h - DESC_R;
@@ -1736,7 +1725,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
       if (interior) {
         // no test can be skipped: lround as float arithmetic (trunc(v) + trunc(2 * frac), exact), the
         // table index as one exact fma, the constant part of the index in the instruction offset
-        const uint16_t* tbl = &lds.box[18 * DESC_HP + 18 + off];
+        const uint16_t* tbl = &lds.hs[18 * DESC_HP + 18 + off];
         // both points of a test side by side in the packed-f32 lanes (v_pk_mul/add/fma_f32);
         // no contraction (the TU is built with -ffp-contract=off), so each product and sum
         // rounds like the reference's scalar code
@@ -1759,8 +1748,8 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
           const int cx1 = jb.x + dx1, cy1 = jb.y + dy1, cx2 = jb.x + dx2, cy2 = jb.y + dy2;
           const bool ok = !(cx1 < 2 || cy1 < 2 || cx1 > jb.w - 1 || cy1 > jb.h - 1 || cx2 < 2 || cy2 < 2 ||
                             cx2 > jb.w - 1 || cy2 > jb.h - 1);
-          const int s1 = lds.box[(dy1 + 18) * DESC_HP + dx1 + 18 + off];
-          const int s2 = lds.box[(dy2 + 18) * DESC_HP + dx2 + 18 + off];
+          const int s1 = lds.hs[(dy1 + 18) * DESC_HP + dx1 + 18 + off];
+          const int s2 = lds.hs[(dy2 + 18) * DESC_HP + dx2 + 18 + off];
           d[k] = __ballot(ok && s1 < s2);
         }
       }
