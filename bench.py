@@ -34,7 +34,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch (KITTI workload, batch 64) from separate rocprofv3 --pmc passes,
 # see profiles/r01/pmc_traffic.md for the raw counters and the correction applied
-PMC_TRAFFIC = {"k_blur": 209.0e6, "k_fast_nms": 134.7e6, "k_fast_nms_full_work": 317.8e6}
+PMC_TRAFFIC = {"k_blur": 209.4e6, "k_fast_nms": 28.4e6, "k_fast_nms_full_work": 79.3e6}
 
 
 def stream_a(n, first=0):
