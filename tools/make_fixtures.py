@@ -11,6 +11,11 @@ Outputs (all data, no reference source text):
       the 256x4 learned ORB test-pair table (x1,y1,x2,y2 per bit), i.e. the
       numeric contents of bit_pattern_31_ (src/orb_pattern.cpp:4-260), written
       as a flat comma-separated int8 list, 16 numbers per line.
+  tests/golden/kitti_000000.png
+      the reference's 000000.png itself (a data file), for the PNG reader.
+  tests/golden/matching_orb_{gt_path,est_path,scale}.txt
+      the first 120 lines of results/matching_orb/*.txt (data written by the
+      reference's savePaths, src/feature_matching.cpp:295-322).
 """
 import hashlib
 import os
@@ -61,6 +66,16 @@ def main():
         with open(os.path.join(ROOT, rel), "w") as f:
             f.write(text)
     np.save(os.path.join(ROOT, "tests", "golden", "pattern_31.npy"), np.array(vals, dtype=np.int8).reshape(256, 4))
+    # I/O formats: one of the reference's own PNG frames, byte for byte (a data
+    # file), and the head of the trajectory files one of its runs wrote (results/matching_orb/*.txt,
+    # the format metric.py:49-51 reads back)
+    import shutil
+
+    shutil.copyfile(os.path.join(REF, "000000.png"), os.path.join(ROOT, "tests", "golden", "kitti_000000.png"))
+    for name in ("gt_path.txt", "est_path.txt", "scale.txt"):
+        lines = open(os.path.join(REF, "results", "matching_orb", name)).read().splitlines(True)[:120]
+        with open(os.path.join(ROOT, "tests", "golden", "matching_orb_" + name), "w") as f:
+            f.writelines(lines)
     print("pattern sha256", hashlib.sha256(np.array(vals, dtype=np.int8).tobytes()).hexdigest()[:16])
 
 
