@@ -251,6 +251,10 @@ void build_frame_tiles(const OrbxPlan& plan, int tw, int th, bool pyramid_fields
   out->clear();
   for (int l = 0; l < plan.nlevels; l++) {
     const OrbxLevel& L = plan.L[l];
+    // pyramid tiles: 8 rows per wave where a lane keeps only 4 registers per row in flight
+    // (level 0 copy, 8-byte-window levels), else 4
+    const int rpw = pyramid_fields ? ((l == 0 || L.win8) ? 8 : 4) : 0;
+    if (pyramid_fields) th = 4 * rpw;
     const int ntx = (L.pitch + tw - 1) / tw, nty = (L.h + th - 1) / th;
     for (int ty = 0; ty < nty; ty++)
       for (int tx = 0; tx < ntx; tx++) {
@@ -258,6 +262,7 @@ void build_frame_tiles(const OrbxPlan& plan, int tw, int th, bool pyramid_fields
         d.l = l;
         d.tx = tx;
         d.ty = ty;
+        d.f = rpw;
         d.w = L.w;
         d.h = L.h;
         d.pitch = L.pitch;

@@ -102,9 +102,10 @@ struct OrbxFastParams {
 #define ORBX_BLUR2_TW 248
 #define ORBX_BLUR2_TH 64
 int orbx_blur2_rows_per_wave();  // 16 or 32; tile height of k_blur2 = 4x this
-// pyramid kernel: a wave owns 256 x 4 pixels, a workgroup 256 x 16
+// pyramid kernel: a wave owns 256 x 8 pixels (level 0 and the levels resized through 8-byte
+// windows) or 256 x 4, a workgroup four times that; OrbxTileDesc::f carries the rows per wave
 #define ORBX_PYR2_TW 256
-#define ORBX_PYR2_TH 16
+#define ORBX_PYR2_TH 16  // smallest tile height (sizes the tile table pool)
 
 #define ORBX_MAX_SELECT 4096  // largest per-level FAST cap the selection kernel holds in LDS (16 B per candidate)
 

@@ -101,9 +101,86 @@ struct __attribute__((packed, aligned(1))) uint2_unaligned {
   uint32_t x, y;
   __device__ operator uint2() const { return make_uint2(x, y); }
 };
-#define PYR2_ROWS 4    // output rows per group
-#define PYR2_GROUPS 1  // groups per wave (2 measured slower: 70 vs 65 us)
-static_assert(ORBX_PYR2_TH == 4 * PYR2_ROWS * PYR2_GROUPS, "tile height = 4 waves x groups x rows");
+
+// ROWS output rows of a lane's four pixels.  WIN8: levels with scale <= 2, where the four
+// source pairs of a lane lie inside one 8-byte window (host-verified per level), so ONE
+// unaligned 8-byte load per source row replaces four 2-byte gathers and v_perm picks each pair
+// out of it (only 4 registers per output row are in flight, which is what lets a wave own 8
+// rows); else four 2-byte pair gathers per source row.
+template <int ROWS, bool WIN8>
+__device__ __forceinline__ void pyr_rows(const uint8_t* __restrict__ src, int in_stride, int w0, int h0,
+                                         const OrbxResizeTap* __restrict__ ytaps, int yb, int lh,
+                                         const uint32_t (&ofs)[4], const uint32_t (&cc)[4],
+                                         __amdgpu_buffer_rsrc_t rout, uint32_t voff_st, uint32_t vmask, int pitch) {
+  constexpr int NW = WIN8 ? 2 : 4;  // dwords in flight per source row
+  uint32_t q0[ROWS][NW], q1[ROWS][NW];
+  int b0[ROWS], b1[ROWS];
+  uint32_t sel[4];
+  uint32_t base = 0;
+  if (WIN8) {
+    // the window start is clamped so that it never reads past the source row
+    base = min(ofs[0], (uint32_t)(w0 - 8));
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t sb = ofs[k] - base;               // 0..6
+      sel[k] = 0x0c000c00u | ((sb + 1) << 16) | sb;  // (src[ofs], src[ofs+1]) as two u16 lanes
+    }
+  }
+  // every gather of the wave is in flight before the first is used
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    const int y = min(yb + r, lh - 1);         // rows past the level repeat the last one (not stored)
+    const OrbxResizeTap ty_ = ytaps[y];        // wave-uniform -> scalar load
+    const int sy0 = min(max(ty_.ofs, 0), h0 - 1), sy1 = min(max(ty_.ofs + 1, 0), h0 - 1);
+    const uint8_t* S0 = src + (size_t)sy0 * in_stride;
+    const uint8_t* S1 = src + (size_t)sy1 * in_stride;
+    b0[r] = ty_.c0;
+    b1[r] = ty_.c1;
+    if (WIN8) {
+      const uint2 a = *reinterpret_cast<const uint2_unaligned*>(S0 + base);
+      const uint2 b = *reinterpret_cast<const uint2_unaligned*>(S1 + base);
+      q0[r][0] = a.x;
+      q0[r][1] = a.y;
+      q1[r][0] = b.x;
+      q1[r][1] = b.y;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        // ofs <= w0-2 always (host table): one unaligned 16-bit load fetches src[ofs], src[ofs+1]
+        q0[r][k] = *reinterpret_cast<const u16_unaligned*>(S0 + ofs[k]);
+        q1[r][k] = *reinterpret_cast<const u16_unaligned*>(S1 + ofs[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    uint32_t out = 0;
+    const uint32_t bs0 = ((uint32_t)b0[r] << 12) & 0xffffffu, bs1 = ((uint32_t)b1[r] << 12) & 0xffffffu;  // b <= 2048
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t p0, p1;  // the pixel pair as two u16 lanes
+      if (WIN8) {
+        p0 = __builtin_amdgcn_perm(q0[r][1], q0[r][0], sel[k]);
+        p1 = __builtin_amdgcn_perm(q1[r][1], q1[r][0], sel[k]);
+      } else {
+        p0 = __builtin_amdgcn_perm(q0[r][k], q0[r][k], 0x0c010c00u);
+        p1 = __builtin_amdgcn_perm(q1[r][k], q1[r][k], 0x0c010c00u);
+      }
+      // horizontal pass: src[ofs] * c0 + src[ofs+1] * c1 is one v_dot2_u32_u16 of the pixel
+      // pair with the tap's packed (c0, c1)
+      const us2_t cw = __builtin_bit_cast(us2_t, cc[k]);
+      const uint32_t r0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, p0), cw, 0u, false);
+      const uint32_t r1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, p1), cw, 0u, false);
+      // vertical pass: (b * (r >> 4)) >> 16 == ((r & ~15) * (b << 12)) >> 32 with both factors
+      // below 2^24: one v_and + one full-rate v_mul_hi_u32_u24 per term; the sum is <= 1022
+      const uint32_t t0 = (uint32_t)(((u64)(r0 & 0xfffff0u) * (u64)bs0) >> 32);
+      const uint32_t t1 = (uint32_t)(((u64)(r1 & 0xfffff0u) * (u64)bs1) >> 32);
+      out |= ((t0 + t1 + 2u) >> 2) << (8 * k);
+    }
+    const int y = yb + r;
+    if (y < lh) __builtin_amdgcn_raw_buffer_store_b32(out & vmask, rout, voff_st, y * pitch, 0);
+  }
+}
 
 __global__ __launch_bounds__(256) void k_pyramid2(const OrbxTileDesc* __restrict__ tiles, int frame_bytes, int w0,
                                                   int h0, const uint8_t* __restrict__ in, int in_stride,
@@ -113,17 +190,15 @@ __global__ __launch_bounds__(256) void k_pyramid2(const OrbxTileDesc* __restrict
   struct {
     int w, h, pitch, xtab_off, ytab_off, win8;
   } L = {d.w, d.h, d.pitch, d.u0, d.u1, d.u2};
-  struct {
-    int w0, h0;
-  } plan = {w0, h0};
   const int l = d.l, tx = d.tx, ty = d.ty;
+  const int rpw = d.f;  // rows per wave of this level's tiles: 8 (level 0, 8-byte-window levels) or 4
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint8_t* src = in + (size_t)f * in_frame_stride;
   const int x = tx * 256 + lane * 4;
-  const int yb0 = ty * ORBX_PYR2_TH + wave * (PYR2_ROWS * PYR2_GROUPS);
-  if (yb0 >= L.h) return;  // whole wave
+  const int yb = (ty * 4 + wave) * rpw;
+  if (yb >= L.h) return;  // whole wave
   const int pitch = L.pitch, w = L.w;
   const __amdgpu_buffer_rsrc_t rout =
       __builtin_amdgcn_make_buffer_rsrc(pyr + (size_t)f * frame_bytes + d.img_off, 0, pitch * L.h, 0x00020000);
@@ -133,9 +208,9 @@ __global__ __launch_bounds__(256) void k_pyramid2(const OrbxTileDesc* __restrict
 
   if (l == 0) {  // level 0 = the input frame (src/orb.cpp:112), re-pitched
 #pragma unroll
-    for (int r = 0; r < PYR2_ROWS * PYR2_GROUPS; r++) {
-      const int y = yb0 + r;
-      if (y < L.h) {
+    for (int r = 0; r < 8; r++) {
+      const int y = yb + r;
+      if (r < rpw && y < L.h) {
         const uint8_t* row = src + (size_t)y * in_stride;
         uint32_t v = 0;
         if (nvalid >= 4 || (nvalid > 0 && y + 1 < L.h)) {
@@ -159,83 +234,14 @@ __global__ __launch_bounds__(256) void k_pyramid2(const OrbxTileDesc* __restrict
     ofs[0] = t01.x; ofs[1] = t01.z; ofs[2] = t23.x; ofs[3] = t23.z;
     cc[0] = t01.y; cc[1] = t01.w; cc[2] = t23.y; cc[3] = t23.w;
   }
-  // a wave serves PYR2_GROUPS groups of PYR2_ROWS rows one after the other: the tile descriptor
-  // and the x taps (two dependent memory round trips) are paid once per wave, the registers
-  // hold one group
-#pragma unroll 1
-  for (int g = 0; g < PYR2_GROUPS; g++) {
-  const int yb = yb0 + g * PYR2_ROWS;
-  if (yb >= L.h) break;
-  // gather phase: 2 source rows x 4 pixel pairs x 4 output rows
-  uint32_t p0[PYR2_ROWS][4], p1[PYR2_ROWS][4];
-  int b0[PYR2_ROWS], b1[PYR2_ROWS];
+  const OrbxResizeTap* ytaps = taps + L.ytab_off;
   if (L.win8) {
-    // Levels with scale <= 2: the four source pairs of a lane lie inside one
-    // 8-byte window (host-verified per level), so ONE unaligned 8-byte load per
-    // source row replaces four 2-byte gathers; v_perm picks each pair out of it.
-    // The window start is clamped so that it never reads past the source row.
-    const uint32_t base = min(ofs[0], (uint32_t)(plan.w0 - 8));
-    uint32_t sel[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint32_t sb = ofs[k] - base;  // 0..6
-      sel[k] = 0x0c000c00u | ((sb + 1) << 16) | sb;  // (src[ofs], src[ofs+1]) as two u16 lanes
-    }
-#pragma unroll
-    for (int r = 0; r < PYR2_ROWS; r++) {
-      const int y = min(yb + r, L.h - 1);
-      const OrbxResizeTap ty_ = taps[L.ytab_off + y];
-      const int sy0 = min(max(ty_.ofs, 0), plan.h0 - 1), sy1 = min(max(ty_.ofs + 1, 0), plan.h0 - 1);
-      const uint2 w0v = *reinterpret_cast<const uint2_unaligned*>(src + (size_t)sy0 * in_stride + base);
-      const uint2 w1v = *reinterpret_cast<const uint2_unaligned*>(src + (size_t)sy1 * in_stride + base);
-      b0[r] = ty_.c0;
-      b1[r] = ty_.c1;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        p0[r][k] = __builtin_amdgcn_perm(w0v.y, w0v.x, sel[k]);
-        p1[r][k] = __builtin_amdgcn_perm(w1v.y, w1v.x, sel[k]);
-      }
-    }
+    if (rpw == 8)
+      pyr_rows<8, true>(src, in_stride, w0, h0, ytaps, yb, L.h, ofs, cc, rout, voff_st, vmask, pitch);
+    else
+      pyr_rows<4, true>(src, in_stride, w0, h0, ytaps, yb, L.h, ofs, cc, rout, voff_st, vmask, pitch);
   } else {
-#pragma unroll
-    for (int r = 0; r < PYR2_ROWS; r++) {
-      const int y = min(yb + r, L.h - 1);  // rows past the level repeat the last one (not stored)
-      const OrbxResizeTap ty_ = taps[L.ytab_off + y];  // wave-uniform -> scalar load
-      const int sy0 = min(max(ty_.ofs, 0), plan.h0 - 1), sy1 = min(max(ty_.ofs + 1, 0), plan.h0 - 1);
-      const uint8_t* S0 = src + (size_t)sy0 * in_stride;
-      const uint8_t* S1 = src + (size_t)sy1 * in_stride;
-      b0[r] = ty_.c0;
-      b1[r] = ty_.c1;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        // ofs <= w0-2 always (host table): one unaligned 16-bit load fetches src[ofs], src[ofs+1]
-        const uint32_t q0 = *reinterpret_cast<const u16_unaligned*>(S0 + ofs[k]);
-        const uint32_t q1 = *reinterpret_cast<const u16_unaligned*>(S1 + ofs[k]);
-        p0[r][k] = __builtin_amdgcn_perm(q0, q0, 0x0c010c00u);
-        p1[r][k] = __builtin_amdgcn_perm(q1, q1, 0x0c010c00u);
-      }
-    }
-  }
-  // horizontal pass: src[ofs] * c0 + src[ofs+1] * c1 is one v_dot2_u32_u16 of the pixel pair
-  // (two u16 lanes) with the tap's packed (c0, c1)
-#pragma unroll
-  for (int r = 0; r < PYR2_ROWS; r++) {
-    uint32_t out = 0;
-    const uint32_t bs0 = ((uint32_t)b0[r] << 12) & 0xffffffu, bs1 = ((uint32_t)b1[r] << 12) & 0xffffffu;  // b <= 2048
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const us2_t cw = __builtin_bit_cast(us2_t, cc[k]);
-      const int r0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, p0[r][k]), cw, 0u, false);
-      const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, p1[r][k]), cw, 0u, false);
-      // (b * (r >> 4)) >> 16 == ((r & ~15) * (b << 12)) >> 32 with both factors below 2^24:
-      // one v_and + one full-rate v_mul_hi_u32_u24 per term; the sum is at most 1022, so no mask
-      const uint32_t t0 = (uint32_t)(((u64)((uint32_t)r0 & 0xfffff0u) * (u64)bs0) >> 32);
-      const uint32_t t1 = (uint32_t)(((u64)((uint32_t)r1 & 0xfffff0u) * (u64)bs1) >> 32);
-      out |= ((t0 + t1 + 2u) >> 2) << (8 * k);
-    }
-    const int y = yb + r;
-    if (y < L.h) __builtin_amdgcn_raw_buffer_store_b32(out & vmask, rout, voff_st, y * pitch, 0);
-  }
+    pyr_rows<4, false>(src, in_stride, w0, h0, ytaps, yb, L.h, ofs, cc, rout, voff_st, vmask, pitch);
   }
 }
 
