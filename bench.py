@@ -221,6 +221,24 @@ def main():
         res = ctx.batch_fetch(0, B, cap)
     dt_d2h = (time.perf_counter() - t1) / nd2h
 
+    # informational (never `value`): two contexts, each with its own stream and pools, fed alternately --
+    # the latency-bound tail of one step (selection, describe) overlaps the front of the next one
+    two_ctx_fps = None
+    if rank == 0 and not args.only_timed:
+        with pkg.Context(p) as ctx2:
+            pair = (ctx, ctx2)
+            for i in range(4):
+                pair[i & 1].batch_device(d_frames.data_ptr(), B, W, H)
+            ctx.wait()
+            ctx2.wait()
+            nst = max(args.steps, 10)
+            t5 = time.perf_counter()
+            for i in range(nst):
+                pair[i & 1].batch_device(d_frames.data_ptr(), B, W, H)
+            ctx.wait()
+            ctx2.wait()
+            two_ctx_fps = B * nst / (time.perf_counter() - t5)
+
     # next row, informational: Hamming 2-NN + ratio test of every consecutive
     # frame pair of the batch, on the device-resident descriptors (not part of `value`)
     match_ms, n_matches = 0.0, 0
@@ -318,6 +336,7 @@ def main():
                            "early_exit_frac": 1.0 - fast_tiles[0] / max(fast_tiles[1], 1)},
             "stage_ms_per_step": stage_ms,
             "fps_with_d2h": world * B / dt_d2h,
+            "fps_two_contexts_alternating": two_ctx_fps,
             "single_frame_host_to_host": single,
             "lk_track": lk,
             "match_consecutive": {"ms_per_batch": match_ms, "pairs": B - 1, "matches_pair0": n_matches,

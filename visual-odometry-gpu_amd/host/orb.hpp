@@ -124,8 +124,12 @@ inline orbx_params cpu_defaults() {
   p.max_height = 8;
   return p;
 }
-inline std::shared_ptr<Ctx>& stage_ctx() {  // shared by the free stage functions
-  static std::shared_ptr<Ctx> c = std::make_shared<Ctx>(gpu_defaults());
+inline std::shared_ptr<Ctx>& stage_ctx() {  // shared by the free stage functions, the matcher and the tracker
+  static std::shared_ptr<Ctx> c = [] {
+    orbx_params p = gpu_defaults();
+    p.nlevels = 1;  // the stage operators work on single images: any size >= 8x8 is a valid plan
+    return std::make_shared<Ctx>(p);
+  }();
   return c;
 }
 inline orbx_keypoint* kp(std::vector<Keypoint>& v) { return reinterpret_cast<orbx_keypoint*>(v.data()); }
