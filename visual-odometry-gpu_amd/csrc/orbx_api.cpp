@@ -91,6 +91,9 @@ struct orbx_ctx {
   int32_t* d_cand_count = nullptr;
   int32_t* d_cand_total = nullptr;
   float* d_resp = nullptr;
+  uint32_t* d_lcand = nullptr;  // spread selection: packed candidates, their responses, counts
+  float* d_lresp = nullptr;
+  int32_t* d_lcount = nullptr;
   OrbxResizeTap* d_taps = nullptr;
   size_t taps_capacity = 0;
   float* d_gauss = nullptr;
@@ -558,8 +561,13 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   // result block sections are laid out for (n, pool slot capacity)
   c->out_layout = make_out_layout(n, P.out_cap > 0 ? P.out_cap : 1);
   const OutLayout& o = c->out_layout;
-  HIPCHK(c, orbx_launch_level_select(s, P, n, c->p.select_mode, c->d_mask, final_pyr(c), c->d_gauss,
-                                     c->p.harris_window, c->p.harris_k, c->d_cand, c->d_resp, c->d_cand_count));
+  static const int spread = [] {  // ORBX_SELECT_SPREAD=0/1 forces the fused / the three-kernel selection (A/B timing)
+    const char* e = getenv("ORBX_SELECT_SPREAD");
+    return e ? atoi(e) : -1;
+  }();
+  HIPCHK(c, orbx_launch_level_select_auto(s, P, n, c->p.select_mode, spread, c->d_mask, final_pyr(c), c->d_gauss,
+                                          c->p.harris_window, c->p.harris_k, c->d_lcand, c->d_lcount, c->d_lresp,
+                                          c->d_cand, c->d_resp, c->d_cand_count));
   HIPCHK(c, mark(6, false));
   if (P.out_cap <= 0)  // nfeatures too small for any quota: no describe launch, so the counts are zeroed here
     HIPCHK(c, hipMemsetAsync(c->d_out + o.counts, 0, sizeof(int32_t) * (size_t)n, s));
@@ -688,7 +696,8 @@ void orbx_destroy(orbx_ctx* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* bufs[] = {c->d_in,   c->d_pyr,  c->d_pyr_blur, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total,
-                  c->d_resp, c->d_taps, c->d_gauss,    c->d_out, c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur2, c->d_tiles_pyr2};
+                  c->d_resp, c->d_taps, c->d_gauss,    c->d_out, c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur2, c->d_tiles_pyr2,
+                  c->d_lcand, c->d_lresp, c->d_lcount};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_out) (void)hipHostFree(c->h_out);
@@ -781,6 +790,9 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
   CREATE_CHK(hipMalloc((void**)&c->d_cand_count, B * ORBX_MAX_LEVELS * sizeof(int32_t)));
   CREATE_CHK(hipMalloc((void**)&c->d_cand_total, B * ORBX_MAX_LEVELS * sizeof(int32_t)));
   CREATE_CHK(hipMalloc((void**)&c->d_resp, B * (size_t)std::max(M.cand_total, 1) * sizeof(float)));
+  CREATE_CHK(hipMalloc((void**)&c->d_lcand, B * (size_t)std::max(M.cand_total, 1) * sizeof(uint32_t)));
+  CREATE_CHK(hipMalloc((void**)&c->d_lresp, B * (size_t)std::max(M.cand_total, 1) * sizeof(float)));
+  CREATE_CHK(hipMalloc((void**)&c->d_lcount, B * ORBX_MAX_LEVELS * sizeof(int32_t)));
   {
     size_t taps = 1;
     for (int l = 1; l < M.nlevels; l++) taps += (size_t)align_up(M.L[l].w, 4) + align_up(M.L[l].h, 4);

@@ -155,6 +155,13 @@ hipError_t orbx_launch_level_select(hipStream_t s, const OrbxPlan& plan, int n_f
                                     const unsigned long long* d_mask, const uint8_t* d_pyr, const float* d_gauss,
                                     int window, float k, orbx_keypoint* d_sel_lkp, float* d_sel_resp,
                                     int32_t* d_sel_count);
+// fused kernel or the three spread kernels, chosen by shape (force: 0 fused, 1 spread, -1 auto);
+// d_cand / d_cresp: cand_total slots per frame, d_ncand: nlevels per frame (spread path only)
+hipError_t orbx_launch_level_select_auto(hipStream_t s, const OrbxPlan& plan, int n_frames, int mode, int force,
+                                         const unsigned long long* d_mask, const uint8_t* d_pyr,
+                                         const float* d_gauss, int window, float k, uint32_t* d_cand,
+                                         int32_t* d_ncand, float* d_cresp, orbx_keypoint* d_sel_lkp,
+                                         float* d_sel_resp, int32_t* d_sel_count);
 hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frames, const uint8_t* d_pyr,
                                 int patch_size, const int32_t* d_sel_count, const orbx_keypoint* d_sel_lkp,
                                 const float* d_sel_resp, int32_t* d_out_count, orbx_keypoint* d_out_lkp,

@@ -1224,6 +1224,145 @@ __global__ __launch_bounds__(LVL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   }
 }
 
+// ---------------------------------------------------------------------------
+// 6c. The same selection as k_level_select, spread over the whole chip.  k_level_select does
+//     everything for one (level, frame) in ONE workgroup, which is the faster arrangement while
+//     a level has at most one candidate per thread (KITTI, 1000 features: 27 us vs 31 us for the
+//     three kernels below at batch 64, 119 vs 134 us for a single frame end to end).  With larger
+//     per-level caps (1920x1080, 4000 features: level 0 has ~1400 candidates) it serialises
+//     Harris and the n^2 ranking inside single workgroups (110 us at batch 16); then three short
+//     kernels take over (79 us; orbx_launch_level_select_auto):
+//       k_lvl_compact  (level, frame)                   first `cap` survivors, row-major
+//       k_lvl_harris   (256 candidates, level, frame)   thread per candidate
+//       k_lvl_rank     (64 candidates, level, frame)    4 threads per candidate
+//     Same arithmetic, same order, same tie rule: results are identical.
+__global__ __launch_bounds__(256) void k_lvl_compact(OrbxPlan plan, const u64* __restrict__ mask,
+                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ ncand) {
+  __shared__ int s_wsum[4][4];
+  const int l = blockIdx.x, f = blockIdx.y;
+  const OrbxLevel& L = plan.L[l];
+  const int cap = L.cap;
+  const u64* m = mask + (size_t)f * plan.mask_words + L.mask_off;
+  uint32_t* out = cand + (size_t)f * plan.cand_total + L.cand_off;
+  const int nwords = L.h * L.mask_wpr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int base = 0;
+  // four 256-word chunks per round: their loads are in flight together (one memory
+  // round trip per 1024 words); words after the first `cap` survivors are never needed
+  for (int w0 = 0; w0 < nwords && base < cap; w0 += 1024) {
+    u64 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int i = w0 + 256 * q + tid;
+      v[q] = i < nwords ? m[i] : 0ull;
+    }
+    int incl[4], c[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      c[q] = __popcll(v[q]);
+      incl[q] = wave_scan_incl(c[q]);
+      if (lane == 63) s_wsum[q][wave] = incl[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int woff = 0, tot = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int sv = s_wsum[q][k];
+        if (k < wave) woff += sv;
+        tot += sv;
+      }
+      int pos = base + woff + incl[q] - c[q];
+      if (c[q] && pos < cap) {
+        const int i = w0 + 256 * q + tid;
+        const int y = i / L.mask_wpr, xw = i - y * L.mask_wpr;
+        u64 w = v[q];
+        while (w && pos < cap) {
+          const int b = __ffsll((long long)w) - 1;
+          w &= w - 1;
+          out[pos++] = ((uint32_t)y << 16) | (uint32_t)(xw * 64 + b);
+        }
+      }
+      base += tot;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) ncand[f * plan.nlevels + l] = base < cap ? base : cap;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_lvl_harris(
+    OrbxPlan plan, const uint8_t* __restrict__ pyr, const float* __restrict__ gauss, int K, float kk,
+    const uint32_t* __restrict__ cand, const int32_t* __restrict__ ncand, float* __restrict__ resp) {
+  const int l = blockIdx.y, f = blockIdx.z;
+  const OrbxLevel& L = plan.L[l];
+  const int n = ncand[f * plan.nlevels + l];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if ((int)blockIdx.x * 256 >= n) return;  // whole workgroup
+  if (i >= n) return;
+  const size_t o = (size_t)f * plan.cand_total + L.cand_off + i;
+  const uint32_t p = cand[o];
+  const uint8_t* img = pyr + (size_t)f * plan.frame_bytes + L.img_off;
+  resp[o] = harris_any(img, L.w, L.h, L.pitch, (int)(p & 0xffffu), (int)(p >> 16), gauss, K, kk);
+}
+
+#define RANK_SLICE 64
+__global__ __launch_bounds__(256) void k_lvl_rank(OrbxPlan plan, const uint32_t* __restrict__ cand,
+                                                  const int32_t* __restrict__ ncand, const float* __restrict__ resp,
+                                                  orbx_keypoint* __restrict__ sel_lkp, float* __restrict__ sel_resp,
+                                                  int32_t* __restrict__ sel_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+  __shared__ int s_part[4][RANK_SLICE];
+  u64* s_key = reinterpret_cast<u64*>(s_dyn);  // [n rounded up to 8]
+  const int l = blockIdx.y, f = blockIdx.z;
+  const OrbxLevel& L = plan.L[l];
+  const int n = ncand[f * plan.nlevels + l];
+  const int keep = n < L.quota ? n : L.quota;
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && tid == 0) sel_count[f * plan.nlevels + l] = keep;
+  const int first = blockIdx.x * RANK_SLICE;
+  if (first >= n) return;  // whole workgroup
+  const size_t co = (size_t)f * plan.cand_total + L.cand_off;
+  // all keys of the (level, frame): (response desc, index asc) as one u64, like k_level_select
+  const int n8 = (n + 7) & ~7;
+  for (int i = tid; i < n8; i += 256) {
+    u64 key = 0ull;  // padding: the smallest key, never outranks anything
+    if (i < n) {
+      uint32_t u = orbx_f2u(resp[co + i]);
+      if (u == 0x80000000u) u = 0u;
+      u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+      key = ((u64)u << 32) | (uint32_t)~(uint32_t)i;
+    }
+    s_key[i] = key;
+  }
+  __syncthreads();
+  // thread (ci, part): candidate first + ci against quarter `part` of the keys
+  const int ci = tid & (RANK_SLICE - 1), part = tid >> 6;
+  const int i = first + ci;
+  const u64 ki = s_key[i < n8 ? i : 0];
+  const int per = n8 / 4;  // multiple of 2
+  int rank = 0;
+  for (int j = part * per; j < (part + 1) * per; j += 2) {
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&s_key[j]);
+    rank += v.x > ki;
+    rank += v.y > ki;
+  }
+  s_part[part][ci] = rank;
+  __syncthreads();
+  if (part == 0 && i < n) {
+    rank = s_part[0][ci] + s_part[1][ci] + s_part[2][ci] + s_part[3][ci];
+    if (rank < keep) {
+      const uint32_t p = cand[co + i];
+      const size_t so = (size_t)f * plan.out_cap + L.out_off;
+      orbx_keypoint kp;
+      kp.x = (int)(p & 0xffffu);
+      kp.y = (int)(p >> 16);
+      sel_lkp[so + rank] = kp;
+      sel_resp[so + rank] = resp[co + i];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_select_flat(const float* __restrict__ resp, int n, int keep,
                                                      int32_t* __restrict__ idx) {
   const int m = n < keep ? n : keep;
@@ -2023,6 +2162,29 @@ hipError_t orbx_launch_level_select(hipStream_t s, const OrbxPlan& plan, int n_f
   dim3 grid(plan.nlevels, n_frames);
   hipLaunchKernelGGL(k_level_select, grid, dim3(LVL_THREADS), lds, s, plan, mode, d_mask, d_pyr, d_gauss, window, k,
                      d_sel_lkp, d_sel_resp, d_sel_count);
+  return ORBX_LAUNCH_CHECK();
+}
+
+// one workgroup per (level, frame) or the three spread kernels, whichever suits the shape
+// (see 6c); force = 0 fused, 1 spread, -1 automatic
+hipError_t orbx_launch_level_select_auto(hipStream_t s, const OrbxPlan& plan, int n_frames, int mode, int force,
+                                         const unsigned long long* d_mask, const uint8_t* d_pyr,
+                                         const float* d_gauss, int window, float k, uint32_t* d_cand,
+                                         int32_t* d_ncand, float* d_cresp, orbx_keypoint* d_sel_lkp,
+                                         float* d_sel_resp, int32_t* d_sel_count) {
+  int maxcap = 2;
+  for (int l = 0; l < plan.nlevels; l++) maxcap = plan.L[l].cap > maxcap ? plan.L[l].cap : maxcap;
+  const bool spread = mode == ORBX_SELECT_HARRIS &&
+                      (force >= 0 ? force != 0 : maxcap > LVL_THREADS);  // more than one candidate per thread
+  if (!spread)
+    return orbx_launch_level_select(s, plan, n_frames, mode, d_mask, d_pyr, d_gauss, window, k, d_sel_lkp,
+                                    d_sel_resp, d_sel_count);
+  hipLaunchKernelGGL(k_lvl_compact, dim3(plan.nlevels, n_frames), dim3(256), 0, s, plan, d_mask, d_cand, d_ncand);
+  hipLaunchKernelGGL(k_lvl_harris, dim3((maxcap + 255) / 256, plan.nlevels, n_frames), dim3(256), 0, s, plan, d_pyr,
+                     d_gauss, window, k, d_cand, d_ncand, d_cresp);
+  const size_t lds = (size_t)((maxcap + 7) & ~7) * 8;
+  hipLaunchKernelGGL(k_lvl_rank, dim3((maxcap + RANK_SLICE - 1) / RANK_SLICE, plan.nlevels, n_frames), dim3(256), lds,
+                     s, plan, d_cand, d_ncand, d_cresp, d_sel_lkp, d_sel_resp, d_sel_count);
   return ORBX_LAUNCH_CHECK();
 }
 
