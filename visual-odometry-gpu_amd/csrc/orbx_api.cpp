@@ -109,7 +109,9 @@ struct orbx_ctx {
   DevBuf m_q, m_t, m_idx, m_dist, m_match, m_cnt;  // matcher (stage API and batch)
   // Lucas-Kanade tracker: two image pyramids (ping-pong: the `next` of one call is the
   // `prev` of the following one), the derivative pyramid of the current `prev`, point buffers
-  DevBuf lk_img[2], lk_deriv, lk_pts, lk_out, lk_st, lk_err;
+  DevBuf lk_img[2], lk_deriv, lk_io;  // lk_io: prev points | next points | err | status, one block
+  void* lk_host = nullptr;            // pinned mirror of lk_io (one H2D + one D2H per call)
+  size_t lk_host_bytes = 0;
   int lk_w = 0, lk_h = 0, lk_top = -1, lk_win = 0, lk_last = -1;  // lk_last: buffer holding the last `next`
   int match_pairs = 0;
 
@@ -703,7 +705,8 @@ void orbx_destroy(orbx_ctx* c) {
   if (c->h_out) (void)hipHostFree(c->h_out);
   DevBuf* sb[] = {&c->s_img_a, &c->s_img_b, &c->s_f32,  &c->s_u16, &c->s_mask, &c->s_kps,   &c->s_f32b, &c->s_desc,
                   &c->s_i32,   &c->s_kern,  &c->s_tiles, &c->m_q,    &c->m_t,   &c->m_idx,  &c->m_dist,  &c->m_match, &c->m_cnt,
-                  &c->lk_img[0], &c->lk_img[1], &c->lk_deriv, &c->lk_pts, &c->lk_out, &c->lk_st, &c->lk_err};
+                  &c->lk_img[0], &c->lk_img[1], &c->lk_deriv, &c->lk_io};
+  if (c->lk_host) (void)hipHostFree(c->lk_host);
   for (DevBuf* b : sb)
     if (b->p) (void)hipFree(b->p);
   for (auto& e : c->ev)
@@ -1527,25 +1530,34 @@ int orbx_lk_track(orbx_ctx* c, const uint8_t* prev, int prev_stride, const uint8
   for (int l = 0; l <= g.top; l++)
     HIPCHK(c, orbx_launch_lk_scharr(c->stream, pimg + g.img_off[l], g.w[l], g.h[l], g.pitch[l],
                                     reinterpret_cast<int16_t*>((uint8_t*)c->lk_deriv.p + g.der_off[l])));
+  uint8_t* hio = nullptr;
+  const size_t o_out = sizeof(float) * 2 * (size_t)n, o_err = 2 * o_out, o_st = o_err + sizeof(float) * (size_t)n;
+  const size_t io_bytes = o_st + (size_t)n;
   if (n > 0) {
-    if ((st = ensure(c, c->lk_pts, sizeof(float) * 2 * (size_t)n)) != ORBX_OK) return st;
-    if ((st = ensure(c, c->lk_out, sizeof(float) * 2 * (size_t)n)) != ORBX_OK) return st;
-    if ((st = ensure(c, c->lk_st, (size_t)n)) != ORBX_OK) return st;
-    if ((st = ensure(c, c->lk_err, sizeof(float) * (size_t)n)) != ORBX_OK) return st;
-    HIPCHK(c, hipMemcpyAsync(c->lk_pts.p, prev_pts_xy, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice,
-                             c->stream));
+    if ((st = ensure(c, c->lk_io, io_bytes)) != ORBX_OK) return st;
+    if (c->lk_host_bytes < io_bytes) {  // pinned staging: small pageable copies cost ~15 us each
+      if (c->lk_host) (void)hipHostFree(c->lk_host);
+      c->lk_host = nullptr;
+      c->lk_host_bytes = 0;
+      HIPCHK(c, hipHostMalloc(&c->lk_host, align_up_sz(io_bytes, 4096), hipHostMallocDefault));
+      c->lk_host_bytes = align_up_sz(io_bytes, 4096);
+    }
+    hio = (uint8_t*)c->lk_host;
+    uint8_t* dio = (uint8_t*)c->lk_io.p;
+    std::memcpy(hio, prev_pts_xy, o_out);
+    HIPCHK(c, hipMemcpyAsync(dio, hio, o_out, hipMemcpyHostToDevice, c->stream));
     const OrbxLkPyr P = lk_pyr(g, pimg, (const uint8_t*)c->lk_deriv.p);
     const OrbxLkPyr N = lk_pyr(g, (const uint8_t*)c->lk_img[in].p, nullptr);
-    HIPCHK(c, orbx_launch_lk_track(c->stream, P, N, n, (const float*)c->lk_pts.p, (float*)c->lk_out.p,
-                                   (uint8_t*)c->lk_st.p, (float*)c->lk_err.p, win_size, max_iters,
-                                   epsilon * epsilon));
-    HIPCHK(c, hipMemcpyAsync(next_pts_xy, c->lk_out.p, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost,
-                             c->stream));
-    HIPCHK(c, hipMemcpyAsync(status, c->lk_st.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    if (err)
-      HIPCHK(c, hipMemcpyAsync(err, c->lk_err.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, orbx_launch_lk_track(c->stream, P, N, n, (const float*)dio, (float*)(dio + o_out), dio + o_st,
+                                   (float*)(dio + o_err), win_size, max_iters, epsilon * epsilon));
+    HIPCHK(c, hipMemcpyAsync(hio + o_out, dio + o_out, io_bytes - o_out, hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n > 0) {
+    std::memcpy(next_pts_xy, hio + o_out, o_out);
+    std::memcpy(status, hio + o_st, (size_t)n);
+    if (err) std::memcpy(err, hio + o_err, sizeof(float) * (size_t)n);
+  }
   c->lk_w = width;
   c->lk_h = height;
   c->lk_top = g.top;

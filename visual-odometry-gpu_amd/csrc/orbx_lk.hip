@@ -121,6 +121,10 @@ __device__ __forceinline__ short2 lk_deriv_at(const OrbxLkLevel& L, int X, int Y
 }
 
 #define LK_MAX_WIN 31
+// one pass over the window items of a lane: unrolled when the trip count is a template constant
+#define LK_ITEM_LOOP                                                                           \
+  _Pragma("unroll 8") for (int it_ = 0, idx = lane; it_ < (NIT ? NIT : (nitem + 63) / 64); it_++, idx += 64) \
+    if (idx < nitem)
 // The Newton steps of a level move the window by fractions of a pixel, so its integer
 // origin hardly ever changes: the (win + 1 + 2 * LK_JC_MARGIN)^2 neighbourhood of the next
 // image is cached in LDS (border reflection resolved while loading) and re-fetched only when
@@ -168,6 +172,10 @@ __device__ __forceinline__ int lk_sample_cached(const LkCache& c, int inx, int i
   return lk_descale(p[0] * w.w00 + p[1] * w.w01 + p[c.jce] * w.w10 + p[c.jce + 1] * w.w11, 14 - 5);
 }
 
+// NIT: passes of the 64 lanes over the win x win window, known at compile time for the
+// reference's 21 x 21 window (7: the loops unroll and the LDS / global reads of a pass set are
+// all in flight together), 0 = run-time trip count for any other window size
+template <int NIT>
 __global__ __launch_bounds__(256) void k_lk_track(OrbxLkPyr P, OrbxLkPyr N, int n, const float2* __restrict__ prev_pts,
                                                   float2* __restrict__ next_pts, uint8_t* __restrict__ status,
                                                   float* __restrict__ err, int win, int max_iters, double eps2) {
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256) void k_lk_track(OrbxLkPyr P, OrbxLkPyr N, int 
     const LkWeights wi = lk_weights(px - (float)ipx, py - (float)ipy);
     const bool in_i = ipx >= 0 && ipy >= 0 && ipx + win + 1 <= I.w && ipy + win + 1 <= I.h;
     int a11 = 0, a12 = 0, a22 = 0;
-    for (int idx = lane; idx < nitem; idx += 64) {
+    LK_ITEM_LOOP {
       const int y = (int)(((uint32_t)idx * rcp) >> 16), x = idx - y * win;
       const int X = ipx + x, Y = ipy + y;
       const int iv = lk_sample(I, X, Y, wi, in_i);
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(256) void k_lk_track(OrbxLkPyr P, OrbxLkPyr N, int 
       const LkWeights wj = lk_weights(nx - (float)inx, ny - (float)iny);
       lk_cache_cover(jc, J, inx, iny, win, lane);
       int b1 = 0, b2 = 0;
-      for (int idx = lane; idx < nitem; idx += 64) {
+      LK_ITEM_LOOP {
         const int y = (int)(((uint32_t)idx * rcp) >> 16), x = idx - y * win;
         const short4 t = tpl[idx];
         const int diff = lk_sample_cached(jc, inx, iny, x, y, wj) - t.x;
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(256) void k_lk_track(OrbxLkPyr P, OrbxLkPyr N, int 
       const LkWeights wj = lk_weights(ex - (float)inx, ey - (float)iny);
       lk_cache_cover(jc, J, inx, iny, win, lane);
       int e = 0;
-      for (int idx = lane; idx < nitem; idx += 64) {
+      LK_ITEM_LOOP {
         const int y = (int)(((uint32_t)idx * rcp) >> 16), x = idx - y * win;
         const int diff = lk_sample_cached(jc, inx, iny, x, y, wj) - tpl[idx].x;
         e += diff < 0 ? -diff : diff;
@@ -329,8 +337,13 @@ hipError_t orbx_launch_lk_track(hipStream_t s, const OrbxLkPyr& prev, const Orbx
                                 int max_iters, double eps2) {
   if (n <= 0) return hipSuccess;
   if (win < 3 || win > LK_MAX_WIN) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_lk_track, dim3((n + 3) / 4), dim3(256), 0, s, prev, next, n,
-                     reinterpret_cast<const float2*>(d_prev_pts), reinterpret_cast<float2*>(d_next_pts), d_status,
-                     d_err, win, max_iters, eps2);
+  const float2* pp = reinterpret_cast<const float2*>(d_prev_pts);
+  float2* np_ = reinterpret_cast<float2*>(d_next_pts);
+  if (win == 21)
+    hipLaunchKernelGGL(k_lk_track<7>, dim3((n + 3) / 4), dim3(256), 0, s, prev, next, n, pp, np_, d_status, d_err, win,
+                       max_iters, eps2);
+  else
+    hipLaunchKernelGGL(k_lk_track<0>, dim3((n + 3) / 4), dim3(256), 0, s, prev, next, n, pp, np_, d_status, d_err, win,
+                       max_iters, eps2);
   return hipGetLastError();
 }
