@@ -402,3 +402,19 @@ def test_zero_feature_budget(pkg, select_mode):
         r = c.batch_fetch(0, 4, 1)
         assert np.array_equal(r["counts"], np.zeros(4, np.int32))
         assert c.detect_and_compute(img)["count"] == 0
+
+
+def test_fast_tile_counts(pkg, kitti0, kitti1):
+    """orbx_fast_tile_counts: with the early exit off every tile works; with it on, fewer do, and the
+    results are the same (checked bit for bit in test_fast_early_exit_is_invisible)."""
+    frames = np.stack([kitti0, kitti1] * 4)
+    p = pkg.default_params("gpu", max_width=1241, max_height=376, max_batch=8, nfeatures=1000, blur_levels=2)
+    with pkg.Context(p) as c:
+        c.set_fast_early_exit(False)
+        c.batch_host(frames)
+        w0, t0 = c.fast_tile_counts()
+        assert w0 == t0 and t0 == 8 * 403  # 403 64x64 tiles over the 8 levels of a 1241x376 frame
+        c.set_fast_early_exit(True)
+        c.batch_host(frames)
+        w1, t1 = c.fast_tile_counts()
+        assert t1 == t0 and 8 * 94 <= w1 < t0  # at least tile row 0 of every level (94 tiles per frame)

@@ -894,8 +894,8 @@ int orbx_fast_tile_counts(orbx_ctx* c, long long* worked, long long* total) {
     for (int l = 0; l < c->plan.nlevels; l++)
       for (int b = 0; b < c->bm_fast.tiles_y[l]; b++)
         w += (long long)(h[(size_t)f * ORBX_FAST_STAT_WORDS + (size_t)l * ORBX_MAX_BANDS + b] >> 32);
-  *worked = w;
   *total = (long long)c->bm_fast.band_begin[c->bm_fast.nbands] * n;
+  *worked = c->fast_early ? w : *total;  // (no statistics are kept when the early exit is off)
   return ORBX_OK;
 }
 
