@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(LVL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
                                                               float* __restrict__ sel_resp,
                                                               int32_t* __restrict__ sel_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-  __shared__ int s_wsum[LVL_THREADS / 64];
+  __shared__ int s_wsum[4][LVL_THREADS / 64];
   const int l = blockIdx.x, f = blockIdx.y;
   const OrbxLevel& L = plan.L[l];
   const int cap = L.cap, cap2 = (cap + 1) & ~1;
@@ -1140,32 +1140,46 @@ __global__ __launch_bounds__(LVL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   const int nwords = L.h * L.mask_wpr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  // phase 1: ordered compaction
+  // phase 1: ordered compaction.  Four chunks of LVL_THREADS words per round: their loads are in
+  // flight together (one memory round trip per 2048 words; level 0 usually needs one round)
   int base = 0;
-  for (int w0 = 0; w0 < nwords && base < cap; w0 += LVL_THREADS) {
-    const int i = w0 + tid;
-    u64 v = i < nwords ? m[i] : 0ull;
-    const int c = __popcll(v);
-    const int incl = wave_scan_incl(c);
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    int woff = 0, tot = 0;
+  for (int w0 = 0; w0 < nwords && base < cap; w0 += 4 * LVL_THREADS) {
+    u64 v[4];
 #pragma unroll
-    for (int k = 0; k < LVL_THREADS / 64; k++) {
-      const int sv = s_wsum[k];
-      if (k < wave) woff += sv;
-      tot += sv;
+    for (int q = 0; q < 4; q++) {
+      const int i = w0 + LVL_THREADS * q + tid;
+      v[q] = i < nwords ? m[i] : 0ull;
     }
-    int pos = base + woff + incl - c;
-    if (c && pos < cap) {
-      const int y = i / L.mask_wpr, xw = i - y * L.mask_wpr;
-      while (v && pos < cap) {
-        const int b = __ffsll((long long)v) - 1;
-        v &= v - 1;
-        s_kp[pos++] = ((uint32_t)y << 16) | (uint32_t)(xw * 64 + b);
+    int incl[4], c[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      c[q] = __popcll(v[q]);
+      incl[q] = wave_scan_incl(c[q]);
+      if (lane == 63) s_wsum[q][wave] = incl[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int woff = 0, tot = 0;
+#pragma unroll
+      for (int k = 0; k < LVL_THREADS / 64; k++) {
+        const int sv = s_wsum[q][k];
+        if (k < wave) woff += sv;
+        tot += sv;
       }
+      int pos = base + woff + incl[q] - c[q];
+      if (c[q] && pos < cap) {
+        const int i = w0 + LVL_THREADS * q + tid;
+        const int y = i / L.mask_wpr, xw = i - y * L.mask_wpr;
+        u64 w = v[q];
+        while (w && pos < cap) {
+          const int b = __ffsll((long long)w) - 1;
+          w &= w - 1;
+          s_kp[pos++] = ((uint32_t)y << 16) | (uint32_t)(xw * 64 + b);
+        }
+      }
+      base += tot;
     }
-    base += tot;
     __syncthreads();
   }
   const int n = base < cap ? base : cap;
