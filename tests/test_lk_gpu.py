@@ -85,3 +85,12 @@ def test_size_sweep_and_errors(ctx, pkg):
     small = np.zeros((10, 10), np.uint8)
     with pytest.raises(pkg.OrbxError):
         ctx.lk_track(None, small, pts[:1])  # no previous call of that geometry
+
+
+def test_min_eigenvalue_borderline_case(ctx):
+    """Found by tools/fuzz_lk.py (seed 5, iteration 53734): a window hanging over the left border whose
+    gradient matrix is almost singular -- the minimum-eigenvalue test then hinges on the last bit of the square
+    root (the device's native sqrt is 1 ulp off; the kernel must use the correctly rounded one)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lk_min_eig_case.npz"))
+    check(ctx, z["a"], z["b"], z["pts"], win=14, max_level=0, max_iters=31, epsilon=0.0)

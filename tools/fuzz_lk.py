@@ -1,5 +1,5 @@
 """Random-configuration parity hunt for the LK tracker: HIP path vs oracle/lk_oracle.c, bit for bit.
-usage: python tools/fuzz_lk.py [seconds] [seed]"""
+usage: python tools/fuzz_lk.py [seconds] [seed] [only_iteration]   (the third argument replays one iteration verbosely)"""
 import importlib, sys, time
 import numpy as np
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
@@ -8,6 +8,7 @@ import oracle_lib as O
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 k0 = O.load_kitti(0)
 p = pkg.default_params("gpu", max_width=64, max_height=64, max_batch=1, nlevels=1)
 t0 = time.time(); it = 0; npts = 0
@@ -33,10 +34,22 @@ with pkg.Context(p) as c:
         pts = np.stack([rng.uniform(-40, w + 40, n), rng.uniform(-40, h + 40, n)], 1).astype(np.float32)
         kw = dict(win=int(rng.integers(3, 32)), max_level=int(rng.integers(0, 8)), max_iters=int(rng.integers(0, 40)),
                   epsilon=float(rng.choice([0.0, 0.001, 0.01, 0.03, 0.5])))
+        if only >= 0 and it != only:
+            it += 1
+            if it > only:
+                break
+            continue
         ro, rs, re, _ = O.lk_track(a, b, pts, **kw)
         go, gs, ge = c.lk_track(a, b, pts, **kw)
         ok = np.array_equal(gs, rs) and np.array_equal(go.view(np.uint32), ro.view(np.uint32)) and \
             np.array_equal(ge.view(np.uint32), re.view(np.uint32))
+        if not ok:
+            bad = np.nonzero((gs != rs) | (go.view(np.uint32) != ro.view(np.uint32)).any(1) | (ge.view(np.uint32) != re.view(np.uint32)))[0]
+            for i in bad[:5]:
+                print("point", i, pts[i], "gpu", go[i], gs[i], ge[i], "oracle", ro[i], rs[i], re[i])
         assert ok, (it, h, w, kind, kw)
+        if only >= 0:
+            print("iteration", it, "ok")
+            break
         it += 1; npts += n
 print("lk fuzz ok: %d configurations, %d points in %.0f s" % (it, npts, time.time() - t0))

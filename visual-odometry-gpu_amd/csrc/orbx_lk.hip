@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_lk_track(OrbxLkPyr P, OrbxLkPyr N, int 
     float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
     const float dif = __fsub_rn(A11, A22);
     const float disc = __fadd_rn(__fmul_rn(dif, dif), __fmul_rn(__fmul_rn(4.f, A12), A12));
-    const float min_eig = __fdiv_rn(__fsub_rn(__fadd_rn(A22, A11), __fsqrt_rn(disc)), (float)(2 * win * win));
+    const float min_eig = __fdiv_rn(__fsub_rn(__fadd_rn(A22, A11), sqrtf(disc)), (float)(2 * win * win));
     if (min_eig < 1e-4f || D < 1.1920928955078125e-07f) {
       if (level == 0) st = 0;
       continue;
