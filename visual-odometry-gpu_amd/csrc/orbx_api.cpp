@@ -58,6 +58,17 @@ OutLayout make_out_layout(int n, int cap) {
 
 }  // namespace
 
+// what a captured launch sequence depends on (run_batch)
+struct OrbxGraphKey {
+  const uint8_t* d_frames;
+  size_t frame_stride;
+  int n, w, h, row_stride, early, plan_serial;
+  bool operator==(const OrbxGraphKey& o) const {
+    return d_frames == o.d_frames && frame_stride == o.frame_stride && n == o.n && w == o.w && h == o.h &&
+           row_stride == o.row_stride && early == o.early && plan_serial == o.plan_serial;
+  }
+};
+
 struct orbx_ctx {
   orbx_params p{};
   int device = 0;
@@ -91,6 +102,10 @@ struct orbx_ctx {
   int32_t* d_cand_count = nullptr;
   int32_t* d_cand_total = nullptr;
   float* d_resp = nullptr;
+  hipGraphExec_t g_exec = nullptr;  // captured launch sequence of the last batch shape (run_batch)
+  bool g_valid = false;
+  OrbxGraphKey g_key{};
+  int plan_serial = 0;  // bumped whenever set_plan rebuilds the plan / tables
   uint32_t* d_lcand = nullptr;  // spread selection: packed candidates, their responses, counts
   float* d_lresp = nullptr;
   int32_t* d_lcount = nullptr;
@@ -469,6 +484,7 @@ int set_plan(orbx_ctx* c, int w, int h) {
     if (!t.empty())
       HIPCHK(c, hipMemcpy(c->d_tiles_fast, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
   }
+  c->plan_serial++;
   c->plan_w = w;
   c->plan_h = h;
   return ORBX_OK;
@@ -532,11 +548,8 @@ hipError_t launch_blur_auto(hipStream_t s, const OrbxPlan& P, const OrbxTileMap&
 }
 const uint8_t* final_pyr(const orbx_ctx* c) { return blur_enabled(c) ? c->d_pyr_blur : c->d_pyr; }
 
-// the whole path for n frames already on the device
-int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row_stride, size_t frame_stride,
-              hipStream_t s) {
-  int st = set_plan(c, w, h);
-  if (st != ORBX_OK) return st;
+// the launches of the whole path for n frames already on the device (the plan is set)
+int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, size_t frame_stride, hipStream_t s) {
   const OrbxPlan& P = c->plan;
   const int tm = c->timing;
   hipEvent_t* evs = c->evr[c->ev_calls % ORBX_EVENT_SETS];
@@ -579,11 +592,56 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
                                  (orbx_keypoint*)(c->d_out + o.kp), (float*)(c->d_out + o.angle),
                                  (orbx_descriptor*)(c->d_out + o.desc)));
   HIPCHK(c, mark(7, false));
-  const int t = tm;
+  return ORBX_OK;
+}
+
+// The launch sequence of a batch depends only on (input pointer and strides, n, plan, switches): it
+// is captured once into a hipGraph and replayed with one hipGraphLaunch per batch (7 enqueues ->
+// 1; matters most for the one-frame-per-call shape, which is launch-bound).  Stage timing needs
+// event records between the kernels, so it takes the plain path.  ORBX_GRAPH=0 disables.
+void drop_graph(orbx_ctx* c) {
+  if (c->g_exec) (void)hipGraphExecDestroy(c->g_exec);
+  c->g_exec = nullptr;
+  c->g_valid = false;
+}
+
+int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row_stride, size_t frame_stride,
+              hipStream_t s) {
+  int st = set_plan(c, w, h);
+  if (st != ORBX_OK) return st;
+  static const int use_graph = [] {
+    const char* e = getenv("ORBX_GRAPH");
+    return e ? atoi(e) : 1;
+  }();
+  const int tm = c->timing;
+  if (use_graph && tm == 0) {
+    const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, c->fast_early ? 1 : 0, c->plan_serial};
+    if (!c->g_valid || !(key == c->g_key)) {
+      drop_graph(c);
+      hipGraph_t g = nullptr;
+      HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      st = enqueue_batch(c, d_frames, n, row_stride, frame_stride, s);
+      const hipError_t ee = hipStreamEndCapture(s, &g);
+      if (st != ORBX_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return st;
+      }
+      HIPCHK(c, ee);
+      const hipError_t ie = hipGraphInstantiate(&c->g_exec, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      HIPCHK(c, ie);
+      c->g_key = key;
+      c->g_valid = true;
+    }
+    HIPCHK(c, hipGraphLaunch(c->g_exec, s));
+  } else {
+    if ((st = enqueue_batch(c, d_frames, n, row_stride, frame_stride, s)) != ORBX_OK) return st;
+  }
+  c->out_layout = make_out_layout(n, c->plan.out_cap > 0 ? c->plan.out_cap : 1);
   c->last_n = n;
   c->last_stream = s;
-  if (t != 0) {
-    c->ev_mode[c->ev_calls % ORBX_EVENT_SETS] = t;
+  if (tm != 0) {
+    c->ev_mode[c->ev_calls % ORBX_EVENT_SETS] = tm;
     c->ev_calls++;
   }
   return ORBX_OK;
@@ -697,6 +755,7 @@ const char* orbx_last_error_string(const orbx_ctx* ctx) { return ctx ? ctx->err.
 void orbx_destroy(orbx_ctx* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->g_exec) (void)hipGraphExecDestroy(c->g_exec);
   void* bufs[] = {c->d_in,   c->d_pyr,  c->d_pyr_blur, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total,
                   c->d_resp, c->d_taps, c->d_gauss,    c->d_out, c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur2, c->d_tiles_pyr2,
                   c->d_lcand, c->d_lresp, c->d_lcount};
