@@ -1597,8 +1597,9 @@ __device__ __forceinline__ void describe_wave(const DescJob& jb, DescLds& lds, i
 //             256 rotated tests, 4 ballots
 //   Keypoints whose whole 41x41 neighbourhood is inside the image (wave-uniform
 //   test) skip the per-test bounds checks.
-#define DESC_KPW 4
-#define DESC_KPB (4 * DESC_KPW)
+// KPW keypoints per wave (template parameter of k_describe2): 4 for throughput (the trig runs in 16 of a
+// workgroup's threads), 1 for the few-keypoint / single-frame case where the chip is nearly empty and the
+// latency of four descriptor passes in a row is what counts
 
 __device__ __forceinline__ void wave_lds_sync() {
   // LDS operations of one wave execute in order; this only pins the compiler
@@ -1709,6 +1710,7 @@ __device__ __forceinline__ f2_t lround_f2(f2_t v) {
   return t + __builtin_elementwise_trunc(fr + fr);
 }
 
+template <int DESC_KPW>
 __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t* __restrict__ pyr, int patch_size,
                                                    const int32_t* __restrict__ sel_count,
                                                    const orbx_keypoint* __restrict__ sel_lkp,
@@ -1720,6 +1722,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
                                                    orbx_keypoint* __restrict__ out_kp,
                                                    float* __restrict__ out_angle,
                                                    orbx_descriptor* __restrict__ out_desc) {
+  constexpr int DESC_KPB = 4 * DESC_KPW;
   __shared__ __attribute__((aligned(16))) DescLds s_lds[4];
   __shared__ int s_m[DESC_KPB][2];
   __shared__ float s_cs[DESC_KPB][2];
@@ -2208,9 +2211,17 @@ hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frame
                                 float* d_out_resp, int32_t* d_out_level, orbx_keypoint* d_out_kp, float* d_out_angle,
                                 orbx_descriptor* d_out_desc) {
   if (plan.out_cap <= 0) return hipSuccess;
-  dim3 grid((plan.out_cap + DESC_KPB - 1) / DESC_KPB, n_frames);
-  hipLaunchKernelGGL(k_describe2, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp, d_sel_resp,
-                     d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc);
+  // few keypoints in flight (single frames, small batches): one keypoint per wave, four times the
+  // workgroups, a quarter of the serial work per wave; else four per wave
+  if ((long long)plan.out_cap * n_frames <= 8192) {
+    dim3 grid((plan.out_cap + 3) / 4, n_frames);
+    hipLaunchKernelGGL(k_describe2<1>, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
+                       d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc);
+  } else {
+    dim3 grid((plan.out_cap + 15) / 16, n_frames);
+    hipLaunchKernelGGL(k_describe2<4>, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
+                       d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc);
+  }
   return ORBX_LAUNCH_CHECK();
 }
 
