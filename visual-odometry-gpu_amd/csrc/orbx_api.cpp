@@ -102,9 +102,11 @@ struct orbx_ctx {
   int32_t* d_cand_count = nullptr;
   int32_t* d_cand_total = nullptr;
   float* d_resp = nullptr;
-  hipGraphExec_t g_exec = nullptr;  // captured launch sequence of the last batch shape (run_batch)
-  bool g_valid = false;
-  OrbxGraphKey g_key{};
+  // captured launch sequences of the most recent batch shapes (run_batch), round-robin replacement
+  static constexpr int kGraphs = 4;
+  hipGraphExec_t g_exec[kGraphs] = {nullptr, nullptr, nullptr, nullptr};
+  OrbxGraphKey g_key[kGraphs] = {};
+  int g_next = 0;
   int plan_serial = 0;  // bumped whenever set_plan rebuilds the plan / tables
   uint32_t* d_lcand = nullptr;  // spread selection: packed candidates, their responses, counts
   float* d_lresp = nullptr;
@@ -599,10 +601,9 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
 // is captured once into a hipGraph and replayed with one hipGraphLaunch per batch (7 enqueues ->
 // 1; matters most for the one-frame-per-call shape, which is launch-bound).  Stage timing needs
 // event records between the kernels, so it takes the plain path.  ORBX_GRAPH=0 disables.
-void drop_graph(orbx_ctx* c) {
-  if (c->g_exec) (void)hipGraphExecDestroy(c->g_exec);
-  c->g_exec = nullptr;
-  c->g_valid = false;
+void drop_graph(orbx_ctx* c, int i) {
+  if (c->g_exec[i]) (void)hipGraphExecDestroy(c->g_exec[i]);
+  c->g_exec[i] = nullptr;
 }
 
 int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row_stride, size_t frame_stride,
@@ -616,8 +617,13 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   const int tm = c->timing;
   if (use_graph && tm == 0) {
     const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, c->fast_early ? 1 : 0, c->plan_serial};
-    if (!c->g_valid || !(key == c->g_key)) {
-      drop_graph(c);
+    int gi = -1;
+    for (int i = 0; i < orbx_ctx::kGraphs; i++)
+      if (c->g_exec[i] && key == c->g_key[i]) gi = i;
+    if (gi < 0) {
+      gi = c->g_next;
+      c->g_next = (c->g_next + 1) % orbx_ctx::kGraphs;
+      drop_graph(c, gi);
       hipGraph_t g = nullptr;
       HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       st = enqueue_batch(c, d_frames, n, row_stride, frame_stride, s);
@@ -627,13 +633,13 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
         return st;
       }
       HIPCHK(c, ee);
-      const hipError_t ie = hipGraphInstantiate(&c->g_exec, g, nullptr, nullptr, 0);
+      const hipError_t ie = hipGraphInstantiate(&c->g_exec[gi], g, nullptr, nullptr, 0);
       (void)hipGraphDestroy(g);
+      if (ie != hipSuccess) c->g_exec[gi] = nullptr;
       HIPCHK(c, ie);
-      c->g_key = key;
-      c->g_valid = true;
+      c->g_key[gi] = key;
     }
-    HIPCHK(c, hipGraphLaunch(c->g_exec, s));
+    HIPCHK(c, hipGraphLaunch(c->g_exec[gi], s));
   } else {
     if ((st = enqueue_batch(c, d_frames, n, row_stride, frame_stride, s)) != ORBX_OK) return st;
   }
@@ -755,7 +761,7 @@ const char* orbx_last_error_string(const orbx_ctx* ctx) { return ctx ? ctx->err.
 void orbx_destroy(orbx_ctx* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  if (c->g_exec) (void)hipGraphExecDestroy(c->g_exec);
+  for (int i = 0; i < orbx_ctx::kGraphs; i++) drop_graph(c, i);
   void* bufs[] = {c->d_in,   c->d_pyr,  c->d_pyr_blur, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total,
                   c->d_resp, c->d_taps, c->d_gauss,    c->d_out, c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur2, c->d_tiles_pyr2,
                   c->d_lcand, c->d_lresp, c->d_lcount};
