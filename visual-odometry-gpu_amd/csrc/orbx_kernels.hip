@@ -721,15 +721,19 @@ __global__ __launch_bounds__(256) void k_fast_nms2(const OrbxTileDesc* __restric
                           p[3 * F2_IMG_PITCH - 1],  p[2 * F2_IMG_PITCH - 2],  p[F2_IMG_PITCH - 3],
                           p[-3],                    p[-F2_IMG_PITCH - 3],     p[-2 * F2_IMG_PITCH - 2],
                           p[-3 * F2_IMG_PITCH - 1]};
-    uint32_t bmk = 0, dmk = 0;
+    // the sign bits of (v - hi) and (lo - v) are shifted into the masks with one v_alignbit each
+    // (2 ops per ring pixel and mask instead of compare + select + shift-or); the masks come out
+    // inverted and in reverse ring order, which a circular run test does not mind
+    uint32_t nb = 0, nd = 0;
     int score = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int v = ring[k];
-      bmk |= (uint32_t)(v >= hi) << k;
-      dmk |= (uint32_t)(v <= lo) << k;
+      nb = __builtin_amdgcn_alignbit(nb, (uint32_t)(v - hi), 31);  // bit = v < hi
+      nd = __builtin_amdgcn_alignbit(nd, (uint32_t)(lo - v), 31);  // bit = v > lo
       score += abs(Ip - v);
     }
+    const uint32_t bmk = ~nb & 0xffffu, dmk = ~nd & 0xffffu;
     if (has_run16(bmk, fp.n) || has_run16(dmk, fp.n)) s_score[pos] = (uint16_t)score;
   };
   // position of candidate bit `bpos` of this thread (same mapping as the compaction above)
