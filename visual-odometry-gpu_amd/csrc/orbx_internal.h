@@ -63,11 +63,12 @@ struct OrbxBandMap {
 // tile kernel needs to know about its tile.  Replaces the chains of dependent
 // scalar loads that decoding blockIdx through the plan / tile maps costs at the
 // start of every wave (~20 s_load round trips for the FAST kernel).
-//   FAST table   : one entry per (band, frame, level, tx) in band-major order;
-//                  img_off / mask_off include the frame.
-//   blur/pyramid : one entry per (level, tx, ty) of ONE frame (blockIdx.y = frame);
-//                  img_off is the level's offset inside a pyramid frame and
-//                  u0/u1/u2 carry xtab_off / ytab_off / win8 (pyramid only).
+//   FAST table   : one entry per (tile row, level, tx) of ONE frame in band-major order
+//                  (grid = frames x tiles, frame index dispatched fastest); `f` = tiles the
+//                  workgroup owns along its tile row (1 in production).
+//   blur/pyramid : one entry per (level, tx, ty) of ONE frame (blockIdx.y = frame); u0/u1/u2
+//                  carry xtab_off / ytab_off / win8 and `f` the rows per wave (pyramid only).
+//   img_off / mask_off are offsets inside one frame's pyramid / mask block.
 struct OrbxTileDesc {
   int32_t l, tx, ty, f;
   int32_t w, h, pitch;

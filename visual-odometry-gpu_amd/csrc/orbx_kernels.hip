@@ -564,8 +564,9 @@ __global__ __launch_bounds__(256) void k_fast_nms2(const OrbxTileDesc* __restric
   struct {
     int w, h, pitch, cap, mask_wpr;
   } L = {d.w, d.h, d.pitch, d.u0, d.u1};
-  // the workgroup owns the tiles tx_first .. tx_first + n_strip - 1 of tile row ty (one
-  // tile in tile row 0, a strip of tiles further down, where most workgroups only exit)
+  // the workgroup owns the tiles tx_first .. tx_first + n_strip - 1 of tile row ty.  The
+  // production table gives every workgroup ONE tile: strips of several tiles were measured
+  // slower (their later tile rows start before the row above is complete)
   const int tx_first = d.tx, ty = d.ty, tiles_x = d.u2, n_strip = d.f;
   const uint8_t* img = pyr + ((size_t)f * (size_t)frame_bytes + d.img_off);
   const int tid = threadIdx.x;
