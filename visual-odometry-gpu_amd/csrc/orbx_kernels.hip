@@ -371,12 +371,13 @@ __device__ __forceinline__ uint32_t pk_mad(uint32_t a, unsigned short m, uint32_
   const us2_t mm = {m, m};
   return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) * mm + __builtin_bit_cast(us2_t, c)));
 }
-// round-half-even of S/256 on both 16-bit lanes
-__device__ __forceinline__ uint32_t pk_rne8(uint32_t S) {
+// round-half-even of S/256 on both 16-bit lanes: the result is the HIGH byte of each lane of
+// S + 127 + ((S >> 8) & 1)  (no final shift: one v_perm gathers the four high bytes of the even
+// and odd pixel pairs straight into the output dword)
+__device__ __forceinline__ uint32_t pk_rne8_hi(uint32_t S) {
   const us2_t s = __builtin_bit_cast(us2_t, S);
   const us2_t one = {1, 1}, c127 = {127, 127};
-  const us2_t r = (us2_t)(s + c127 + ((s >> 8) & one)) >> 8;
-  return __builtin_bit_cast(uint32_t, r);
+  return __builtin_bit_cast(uint32_t, (us2_t)(s + c127 + ((s >> 8) & one)));
 }
 
 // wave-uniform REFLECT_101 on scalars (row index)
@@ -385,6 +386,46 @@ __device__ __forceinline__ int reflect101_s(int p, int len) {
   p = p >= len ? 2 * len - p - 2 : p;
   p = p < 0 ? 0 : p;
   return p >= len ? len - 1 : p;
+}
+
+// the rows of one wave's strip: horizontal pass per incoming row, vertical pass over the five
+// most recent H rows.  PATCH: the wave holds x = 0 or the image's last pixel and applies the
+// REFLECT_101 column selectors (three extra v_perm per row); interior waves skip them.
+template <int RH, bool PATCH>
+__device__ __forceinline__ void blur2_rows(const uint32_t (&Craw)[RH + 4], uint32_t selL, uint32_t selC, uint32_t selR,
+                                           uint32_t vmask, __amdgpu_buffer_rsrc_t rout, uint32_t voff_st, int ya,
+                                           int h, int pitch) {
+  uint32_t he[5], ho[5];
+#pragma unroll
+  for (int i = 0; i < RH + 4; i++) {
+    const uint32_t C0 = Craw[i];
+    const uint32_t Ld = __builtin_amdgcn_update_dpp(C0, C0, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+    const uint32_t Lw = PATCH ? __builtin_amdgcn_perm(C0, Ld, selL) : Ld;
+    const uint32_t C = PATCH ? __builtin_amdgcn_perm(C0, Lw, selC) : C0;
+    const uint32_t Rd = __builtin_amdgcn_update_dpp(C, C, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+    const uint32_t Rw = PATCH ? __builtin_amdgcn_perm(C0, Rd, selR) : Rd;
+
+    // byte pairs (16-bit lanes): perm bytes 0-3 = 2nd argument, 4-7 = 1st
+    const uint32_t A = __builtin_amdgcn_perm(C, Lw, 0x0c040c02u);   // (L.b2, C.b0)
+    const uint32_t B = __builtin_amdgcn_perm(C, Lw, 0x0c050c03u);   // (L.b3, C.b1)
+    const uint32_t Cc = __builtin_amdgcn_perm(C, C, 0x0c020c00u);   // (C.b0, C.b2)
+    const uint32_t D = __builtin_amdgcn_perm(C, C, 0x0c030c01u);    // (C.b1, C.b3)
+    const uint32_t E = __builtin_amdgcn_perm(Rw, C, 0x0c040c02u);   // (C.b2, R.b0)
+    const uint32_t F = __builtin_amdgcn_perm(Rw, C, 0x0c050c03u);   // (C.b3, R.b1)
+    he[i % 5] = pk_mad(pk_add(B, D), 4, pk_mad(Cc, 6, pk_add(A, E)));   // pixels 0,2
+    ho[i % 5] = pk_mad(pk_add(Cc, E), 4, pk_mad(D, 6, pk_add(B, F)));   // pixels 1,3
+    if (i >= 4) {
+      const int y = ya + i - 4;
+      // window rows y-2..y+2 are slots (i-4)%5 .. i%5
+      const uint32_t te = pk_rne8_hi(pk_mad(pk_add(he[(i - 3) % 5], he[(i - 1) % 5]), 4,
+                                            pk_mad(he[(i - 2) % 5], 6, pk_add(he[(i - 4) % 5], he[i % 5]))));
+      const uint32_t to = pk_rne8_hi(pk_mad(pk_add(ho[(i - 3) % 5], ho[(i - 1) % 5]), 4,
+                                            pk_mad(ho[(i - 2) % 5], 6, pk_add(ho[(i - 4) % 5], ho[i % 5]))));
+      // bytes: px0 = te lane0 high byte, px1 = to lane0 high, px2 = te lane1 high, px3 = to lane1 high
+      const uint32_t out = __builtin_amdgcn_perm(to, te, 0x07030501u);
+      if (y < h) __builtin_amdgcn_raw_buffer_store_b32(out & vmask, rout, voff_st, y * pitch, 0);
+    }
+  }
 }
 
 template <int RH>
@@ -450,35 +491,13 @@ __global__ __launch_bounds__(256) void k_blur2(const OrbxTileDesc* __restrict__ 
   const int nvalid = L.w - x;
   const uint32_t vmask = nvalid >= 4 ? 0xffffffffu : nvalid <= 0 ? 0u : ((1u << (8 * nvalid)) - 1u);
 
-  uint32_t he[5], ho[5];
-#pragma unroll
-  for (int i = 0; i < RH + 4; i++) {
-    const uint32_t C0 = Craw[i];
-    const uint32_t Ld = __builtin_amdgcn_update_dpp(C0, C0, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
-    const uint32_t Lw = __builtin_amdgcn_perm(C0, Ld, selL);
-    const uint32_t C = __builtin_amdgcn_perm(C0, Lw, selC);
-    const uint32_t Rd = __builtin_amdgcn_update_dpp(C, C, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
-    const uint32_t Rw = __builtin_amdgcn_perm(C0, Rd, selR);
-
-    // byte pairs (16-bit lanes): perm bytes 0-3 = 2nd argument, 4-7 = 1st
-    const uint32_t A = __builtin_amdgcn_perm(C, Lw, 0x0c040c02u);   // (L.b2, C.b0)
-    const uint32_t B = __builtin_amdgcn_perm(C, Lw, 0x0c050c03u);   // (L.b3, C.b1)
-    const uint32_t Cc = __builtin_amdgcn_perm(C, C, 0x0c020c00u);   // (C.b0, C.b2)
-    const uint32_t D = __builtin_amdgcn_perm(C, C, 0x0c030c01u);    // (C.b1, C.b3)
-    const uint32_t E = __builtin_amdgcn_perm(Rw, C, 0x0c040c02u);   // (C.b2, R.b0)
-    const uint32_t F = __builtin_amdgcn_perm(Rw, C, 0x0c050c03u);   // (C.b3, R.b1)
-    he[i % 5] = pk_mad(pk_add(B, D), 4, pk_mad(Cc, 6, pk_add(A, E)));   // pixels 0,2
-    ho[i % 5] = pk_mad(pk_add(Cc, E), 4, pk_mad(D, 6, pk_add(B, F)));   // pixels 1,3
-    if (i >= 4) {
-      const int y = ya + i - 4;
-      // window rows y-2..y+2 are slots (i-4)%5 .. i%5
-      const uint32_t ve = pk_rne8(pk_mad(pk_add(he[(i - 3) % 5], he[(i - 1) % 5]), 4,
-                                         pk_mad(he[(i - 2) % 5], 6, pk_add(he[(i - 4) % 5], he[i % 5]))));
-      const uint32_t vo = pk_rne8(pk_mad(pk_add(ho[(i - 3) % 5], ho[(i - 1) % 5]), 4,
-                                         pk_mad(ho[(i - 2) % 5], 6, pk_add(ho[(i - 4) % 5], ho[i % 5]))));
-      if (y < h) __builtin_amdgcn_raw_buffer_store_b32((ve | (vo << 8)) & vmask, rout, voff_st, y * pitch, 0);
-    }
-  }
+  // only the waves that hold x = 0 or the image's last pixel need the column patches
+  const int x_lo = tx * BL2_TW - 4, x_hi = x_lo + 4 * 63;
+  const bool patch = (x_lo <= 0) || (e4 >= x_lo && e4 <= x_hi);  // wave-uniform
+  if (patch)
+    blur2_rows<RH, true>(Craw, selL, selC, selR, vmask, rout, voff_st, ya, h, pitch);
+  else
+    blur2_rows<RH, false>(Craw, selL, selC, selR, vmask, rout, voff_st, ya, h, pitch);
 }
 
 // ---------------------------------------------------------------------------
