@@ -371,13 +371,24 @@ __device__ __forceinline__ uint32_t pk_mad(uint32_t a, unsigned short m, uint32_
   const us2_t mm = {m, m};
   return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) * mm + __builtin_bit_cast(us2_t, c)));
 }
+// a * k + c on both 16-bit lanes with the packed multiplier in a register the optimiser cannot see
+// through (pk_opaque): a literal 4 would be strength-reduced to shift + add, two instructions
+// where v_pk_mad_u16 is one
+__device__ __forceinline__ uint32_t pk_mad_r(uint32_t a, uint32_t k, uint32_t c) {
+  return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) * __builtin_bit_cast(us2_t, k) +
+                                              __builtin_bit_cast(us2_t, c)));
+}
+__device__ __forceinline__ uint32_t pk_opaque(uint32_t k) {
+  asm volatile("" : "+s"(k));
+  return k;
+}
 // round-half-even of S/256 on both 16-bit lanes: the result is the HIGH byte of each lane of
 // S + 127 + ((S >> 8) & 1)  (no final shift: one v_perm gathers the four high bytes of the even
 // and odd pixel pairs straight into the output dword)
+// (S <= 255 * 256 per lane, so the sums never carry into the neighbouring lane and plain 32-bit
+// operations do: shift, and, one three-input add)
 __device__ __forceinline__ uint32_t pk_rne8_hi(uint32_t S) {
-  const us2_t s = __builtin_bit_cast(us2_t, S);
-  const us2_t one = {1, 1}, c127 = {127, 127};
-  return __builtin_bit_cast(uint32_t, (us2_t)(s + c127 + ((s >> 8) & one)));
+  return S + 0x007f007fu + ((S >> 8) & 0x00010001u);
 }
 
 // wave-uniform REFLECT_101 on scalars (row index)
@@ -396,6 +407,7 @@ __device__ __forceinline__ void blur2_rows(const uint32_t (&Craw)[RH + 4], uint3
                                            uint32_t vmask, __amdgpu_buffer_rsrc_t rout, uint32_t voff_st, int ya,
                                            int h, int pitch) {
   uint32_t he[5], ho[5];
+  const uint32_t k4 = pk_opaque(0x00040004u), k6 = pk_opaque(0x00060006u);
 #pragma unroll
   for (int i = 0; i < RH + 4; i++) {
     const uint32_t C0 = Craw[i];
@@ -412,18 +424,19 @@ __device__ __forceinline__ void blur2_rows(const uint32_t (&Craw)[RH + 4], uint3
     const uint32_t D = __builtin_amdgcn_perm(C, C, 0x0c030c01u);    // (C.b1, C.b3)
     const uint32_t E = __builtin_amdgcn_perm(Rw, C, 0x0c040c02u);   // (C.b2, R.b0)
     const uint32_t F = __builtin_amdgcn_perm(Rw, C, 0x0c050c03u);   // (C.b3, R.b1)
-    he[i % 5] = pk_mad(pk_add(B, D), 4, pk_mad(Cc, 6, pk_add(A, E)));   // pixels 0,2
-    ho[i % 5] = pk_mad(pk_add(Cc, E), 4, pk_mad(D, 6, pk_add(B, F)));   // pixels 1,3
+    he[i % 5] = pk_mad_r(pk_add(B, D), k4, pk_mad_r(Cc, k6, pk_add(A, E)));   // pixels 0,2
+    ho[i % 5] = pk_mad_r(pk_add(Cc, E), k4, pk_mad_r(D, k6, pk_add(B, F)));   // pixels 1,3
     if (i >= 4) {
       const int y = ya + i - 4;
       // window rows y-2..y+2 are slots (i-4)%5 .. i%5
-      const uint32_t te = pk_rne8_hi(pk_mad(pk_add(he[(i - 3) % 5], he[(i - 1) % 5]), 4,
-                                            pk_mad(he[(i - 2) % 5], 6, pk_add(he[(i - 4) % 5], he[i % 5]))));
-      const uint32_t to = pk_rne8_hi(pk_mad(pk_add(ho[(i - 3) % 5], ho[(i - 1) % 5]), 4,
-                                            pk_mad(ho[(i - 2) % 5], 6, pk_add(ho[(i - 4) % 5], ho[i % 5]))));
+      const uint32_t te = pk_rne8_hi(pk_mad_r(pk_add(he[(i - 3) % 5], he[(i - 1) % 5]), k4,
+                                              pk_mad_r(he[(i - 2) % 5], k6, pk_add(he[(i - 4) % 5], he[i % 5]))));
+      const uint32_t to = pk_rne8_hi(pk_mad_r(pk_add(ho[(i - 3) % 5], ho[(i - 1) % 5]), k4,
+                                              pk_mad_r(ho[(i - 2) % 5], k6, pk_add(ho[(i - 4) % 5], ho[i % 5]))));
       // bytes: px0 = te lane0 high byte, px1 = to lane0 high, px2 = te lane1 high, px3 = to lane1 high
       const uint32_t out = __builtin_amdgcn_perm(to, te, 0x07030501u);
-      if (y < h) __builtin_amdgcn_raw_buffer_store_b32(out & vmask, rout, voff_st, y * pitch, 0);
+      // (interior waves lie wholly left of the image's last dword: nothing to mask)
+      if (y < h) __builtin_amdgcn_raw_buffer_store_b32(PATCH ? (out & vmask) : out, rout, voff_st, y * pitch, 0);
     }
   }
 }
