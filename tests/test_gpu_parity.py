@@ -418,3 +418,31 @@ def test_fast_tile_counts(pkg, kitti0, kitti1):
         c.batch_host(frames)
         w1, t1 = c.fast_tile_counts()
         assert t1 == t0 and 8 * 94 <= w1 < t0  # at least tile row 0 of every level (94 tiles per frame)
+
+
+def test_graph_and_plain_launch_paths_agree(pkg, kitti0, kitti1):
+    """run_batch replays a captured hipGraph per batch shape; with stage timing on it takes the plain
+    launch path.  Same results either way, also when batch shapes alternate (graph cache)."""
+    frames = np.stack([kitti0, kitti1, kitti1, kitti0])
+    p = pkg.default_params("gpu", max_width=1241, max_height=376, max_batch=4, nfeatures=700, blur_levels=2)
+    with pkg.Context(p) as c:
+        cap = c.plan(1241, 376)["out_capacity"]
+
+        def run(n):
+            c.batch_host(frames[:n])
+            r = c.batch_fetch(0, n, cap)
+            return [r[k].copy() for k in ("counts", "kps", "angles", "responses", "desc", "levels")]
+
+        ref4, ref1 = run(4), run(1)            # graph path (captured twice)
+        for _ in range(3):                     # alternating shapes: served from the graph cache
+            for n, ref in ((1, ref1), (4, ref4), (2, None), (3, None)):
+                got = run(n)
+                if ref is not None:
+                    assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+        c.enable_stage_timing(1)               # plain path
+        got4, got1 = run(4), run(1)
+        c.enable_stage_timing(0)
+        assert all(np.array_equal(a, b) for a, b in zip(got4, ref4))
+        assert all(np.array_equal(a, b) for a, b in zip(got1, ref1))
+        t = c.last_stage_times()
+        assert t["total"] > 0
