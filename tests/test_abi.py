@@ -96,3 +96,19 @@ def test_product_never_touches_the_oracle():
                 if f.endswith((".py", ".h", ".hpp", ".cpp", ".hip", ".inc")) or f == "Makefile":
                     txt = open(os.path.join(dp, f), errors="ignore").read()
                     assert "oracle_lib" not in txt and "liborb_oracle" not in txt and "orb_oracle.h" not in txt, f
+
+
+def test_no_result_altering_environment_switch_in_the_shipping_library():
+    """A drop-in library must not let an environment variable corrupt its output: the only ORBX_*
+    switches compiled into liborbx.so choose between result-identical implementations."""
+    blob = open(os.path.join(ROOT, "visual-odometry-gpu_amd", "liborbx.so"), "rb").read()
+    # whole C strings only (getenv names); macro names inside error-message text are not switches
+    found = set(m.decode() for m in re.findall(rb"\x00(ORBX_[A-Z0-9_]{3,})(?=\x00)", blob))
+    allowed = {
+        "ORBX_FAST_EARLY",     # 0: every FAST tile does the full work (tests/test_gpu_parity.py: bit-equal)
+        "ORBX_GRAPH",          # 0: plain launches instead of the captured hipGraph
+        "ORBX_SELECT_SPREAD",  # fused vs three-kernel selection
+        "ORBX_BLUR_IMPL",      # first- vs second-generation separable blur kernel
+        "ORBX_BLUR2_RH",       # rows per wave of the streaming blur
+    }
+    assert found <= allowed, sorted(found - allowed)

@@ -144,6 +144,27 @@ struct orbx_ctx {
 
 namespace {
 
+// Every entry point that takes a context runs on the context's device, whatever the caller's
+// current device is (another context's, torch.cuda.set_device, ...), and leaves the caller's
+// current device as it found it.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(const orbx_ctx* c) {
+    if (!c) return;
+    enter(c->device);
+  }
+  explicit DeviceGuard(int dev) { enter(dev); }
+  void enter(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 int fail(orbx_ctx* c, int status, const std::string& msg) {
   if (c)
     c->err = msg;
@@ -163,6 +184,7 @@ int ensure(orbx_ctx* c, DevBuf& b, size_t bytes) {
   if (b.bytes >= bytes && b.p) return ORBX_OK;
   if (b.p) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->last_stream && c->last_stream != c->stream) HIPCHK(c, hipStreamSynchronize(c->last_stream));
     HIPCHK(c, hipFree(b.p));
     b.p = nullptr;
     b.bytes = 0;
@@ -462,6 +484,7 @@ int set_plan(orbx_ctx* c, int w, int h) {
   if (c->h_taps.size() > c->taps_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "resize table exceeds pool");
   // the table may still be in use by an in-flight batch of the previous size
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->last_stream && c->last_stream != c->stream) HIPCHK(c, hipStreamSynchronize(c->last_stream));
   HIPCHK(c, hipMemcpy(c->d_taps, c->h_taps.data(), c->h_taps.size() * sizeof(OrbxResizeTap),
                       hipMemcpyHostToDevice));
   c->plan = plan;
@@ -498,13 +521,6 @@ hipError_t launch_pyramid_auto(orbx_ctx* c, hipStream_t s, int n, const uint8_t*
                               d_in, in_stride, in_frame_stride, c->d_taps, c->d_pyr);
 }
 
-int fast_ablate() {  // timing diagnostics only: results are wrong when non-zero
-  static const int v = [] {
-    const char* e = getenv("ORBX_FAST_ABLATE");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
 
 bool blur_enabled(const orbx_ctx* c) { return c->p.blur_levels != ORBX_BLUR_NONE; }
 const uint8_t* final_pyr(const orbx_ctx* c);
@@ -512,12 +528,17 @@ const uint8_t* final_pyr(const orbx_ctx* c);
 // FAST + NMS of the batched path.  Tiles that provably cannot contribute to the
 // first `cap` row-major survivors exit early (see decode_band in the kernels);
 // ORBX_FAST_EARLY=0 disables that (every tile does the full work).
-hipError_t launch_fast_whole(orbx_ctx* c, hipStream_t s, int n, OrbxFastParams fp, bool stats_zeroed = false) {
-  static const int early_env = [] {
+int fast_early_env() {  // ORBX_FAST_EARLY=0: every tile does the full work (results are identical)
+  static const int v = [] {
     const char* e = getenv("ORBX_FAST_EARLY");
     return e ? atoi(e) : 1;
   }();
-  unsigned long long* stat = (early_env && c->fast_early) ? c->d_row_stat : nullptr;
+  return v;
+}
+bool fast_early_on(const orbx_ctx* c) { return fast_early_env() && c->fast_early; }
+
+hipError_t launch_fast_whole(orbx_ctx* c, hipStream_t s, int n, OrbxFastParams fp, bool stats_zeroed = false) {
+  unsigned long long* stat = fast_early_on(c) ? c->d_row_stat : nullptr;
   if (stat && !stats_zeroed) {
     hipError_t e = hipMemsetAsync(stat, 0, (size_t)n * ORBX_FAST_STAT_WORDS * 8, s);
     if (e != hipSuccess) return e;
@@ -536,14 +557,6 @@ hipError_t launch_blur_auto(hipStream_t s, const OrbxPlan& P, const OrbxTileMap&
     const char* e = getenv("ORBX_BLUR_IMPL");
     return e ? atoi(e) : 2;
   }();
-  // ORBX_BLUR_COPY_ALL=1: every level takes the pass-through copy path (known byte
-  // count with this kernel's 4-byte-per-lane access pattern; used to calibrate the
-  // FETCH_SIZE / WRITE_SIZE counters, results are of course not blurred)
-  static const int copy_all = [] {
-    const char* e = getenv("ORBX_BLUR_COPY_ALL");
-    return e ? atoi(e) : 0;
-  }();
-  if (copy_all) first_level = ORBX_MAX_LEVELS;
   if (kind == ORBX_BLUR_SEP16 && impl != 1)
     return orbx_launch_blur2(s, tiles2, ntiles2, P.frame_bytes, n, src, dst, first_level);
   return orbx_launch_blur(s, P, tm1, n, src, dst, first_level, kind);
@@ -570,7 +583,7 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
     HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->d_tiles_blur2, c->blur2_tiles_count, n, c->d_pyr, c->d_pyr_blur,
                                c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
   HIPCHK(c, mark(2, true));
-  OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2, fast_ablate()};
+  OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2};
   HIPCHK(c, launch_fast_whole(c, s, n, fp, true));
   HIPCHK(c, mark(3, true));
   HIPCHK(c, mark(4, false));  // (compaction, Harris and selection are one kernel: its time is the "select" slot)
@@ -608,6 +621,9 @@ void drop_graph(orbx_ctx* c, int i) {
 
 int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row_stride, size_t frame_stride,
               hipStream_t s) {
+  // the pools (pyramids, mask, result block) are reused by every batch: a batch still in
+  // flight on a DIFFERENT stream must have finished before this one may touch them
+  if (c->last_stream && c->last_stream != s) HIPCHK(c, hipStreamSynchronize(c->last_stream));
   int st = set_plan(c, w, h);
   if (st != ORBX_OK) return st;
   static const int use_graph = [] {
@@ -616,7 +632,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   }();
   const int tm = c->timing;
   if (use_graph && tm == 0) {
-    const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, c->fast_early ? 1 : 0, c->plan_serial};
+    const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, fast_early_on(c) ? 1 : 0, c->plan_serial};
     int gi = -1;
     for (int i = 0; i < orbx_ctx::kGraphs; i++)
       if (c->g_exec[i] && key == c->g_key[i]) gi = i;
@@ -759,6 +775,7 @@ const char* orbx_version(void) { return "liborbx 0.1.0 gfx950"; }
 const char* orbx_last_error_string(const orbx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 void orbx_destroy(orbx_ctx* c) {
+  DeviceGuard _dg(c);
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int i = 0; i < orbx_ctx::kGraphs; i++) drop_graph(c, i);
@@ -798,7 +815,11 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   }
   if (dev >= ndev) return fail(nullptr, ORBX_ERR_INVALID_ARG, "device ordinal out of range");
-  if (hipSetDevice(dev) != hipSuccess) return fail(nullptr, ORBX_ERR_NO_DEVICE, "hipSetDevice failed");
+  DeviceGuard dg(dev);  // the caller's current device is restored on every return path
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != dev) return fail(nullptr, ORBX_ERR_NO_DEVICE, "hipSetDevice failed");
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess)
     return fail(nullptr, ORBX_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
@@ -888,6 +909,7 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
 
 int orbx_get_plan(orbx_ctx* c, int width, int height, int32_t* level_w, int32_t* level_h, int32_t* quota,
                   int32_t* fast_cap, float* level_scale_out, int32_t* out_capacity) {
+  DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   OrbxPlan plan;
   std::string why;
@@ -906,6 +928,7 @@ int orbx_get_plan(orbx_ctx* c, int width, int height, int32_t* level_w, int32_t*
 
 int orbx_detect_and_compute_batch_device(orbx_ctx* c, const void* d_frames, int n, int width, int height,
                                          int row_stride, size_t frame_stride, void* stream) {
+  DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   if (!d_frames) return fail(c, ORBX_ERR_INVALID_ARG, "d_frames is NULL");
   if (n < 1 || n > c->p.max_batch) return fail(c, ORBX_ERR_INVALID_ARG, "n outside [1, max_batch]");
@@ -918,6 +941,7 @@ int orbx_detect_and_compute_batch_device(orbx_ctx* c, const void* d_frames, int 
 
 int orbx_detect_and_compute_batch_host(orbx_ctx* c, const uint8_t* frames, int n, int width, int height,
                                        int row_stride, size_t frame_stride) {
+  DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   if (n < 1 || n > c->p.max_batch) return fail(c, ORBX_ERR_INVALID_ARG, "n outside [1, max_batch]");
   int st = check_image(c, frames, width, height, row_stride);
@@ -936,18 +960,21 @@ int orbx_detect_and_compute_batch_host(orbx_ctx* c, const uint8_t* frames, int n
 }
 
 int orbx_wait(orbx_ctx* c) {
+  DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   HIPCHK(c, hipStreamSynchronize(c->last_stream ? c->last_stream : c->stream));
   return ORBX_OK;
 }
 
 int orbx_set_fast_early_exit(orbx_ctx* c, int enable) {
+  DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   c->fast_early = enable != 0;
   return ORBX_OK;
 }
 
 int orbx_fast_tile_counts(orbx_ctx* c, long long* worked, long long* total) {
+  DeviceGuard _dg(c);
   if (!c || !worked || !total) return ORBX_ERR_INVALID_ARG;
   if (c->plan_w == 0 || c->last_n < 1) return fail(c, ORBX_ERR_INVALID_ARG, "run a batch first");
   const int n = c->last_n;
@@ -960,17 +987,19 @@ int orbx_fast_tile_counts(orbx_ctx* c, long long* worked, long long* total) {
       for (int b = 0; b < c->bm_fast.tiles_y[l]; b++)
         w += (long long)(h[(size_t)f * ORBX_FAST_STAT_WORDS + (size_t)l * ORBX_MAX_BANDS + b] >> 32);
   *total = (long long)c->bm_fast.band_begin[c->bm_fast.nbands] * n;
-  *worked = c->fast_early ? w : *total;  // (no statistics are kept when the early exit is off)
+  *worked = fast_early_on(c) ? w : *total;  // (no statistics are kept when the early exit is off)
   return ORBX_OK;
 }
 
 int orbx_enable_stage_timing(orbx_ctx* c, int enable) {
+  DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   c->timing = enable < 0 || enable > 2 ? 1 : enable;
   return ORBX_OK;
 }
 
 int orbx_stage_times_history(orbx_ctx* c, int back, float* ms) {
+  DeviceGuard _dg(c);
   if (!c || !ms) return ORBX_ERR_INVALID_ARG;
   if (back < 0 || back >= ORBX_EVENT_SETS || back >= c->ev_calls)
     return fail(c, ORBX_ERR_INVALID_ARG, "no timed batched call that far back");
@@ -991,6 +1020,7 @@ int orbx_stage_times_history(orbx_ctx* c, int back, float* ms) {
 int orbx_last_stage_times(orbx_ctx* c, float* ms) { return orbx_stage_times_history(c, 0, ms); }
 
 int orbx_batch_results_device(orbx_ctx* c, orbx_batch_view* v) {
+  DeviceGuard _dg(c);
   if (!c || !v) return ORBX_ERR_INVALID_ARG;
   if (c->last_n <= 0) return fail(c, ORBX_ERR_INVALID_ARG, "no batch has been run");
   const OutLayout& o = c->out_layout;
@@ -1009,6 +1039,7 @@ int orbx_batch_results_device(orbx_ctx* c, orbx_batch_view* v) {
 int orbx_batch_fetch(orbx_ctx* c, int first, int n, int32_t* counts, orbx_keypoint* keypoints,
                      float* orientations, orbx_descriptor* descriptors, float* responses, int32_t* levels,
                      orbx_keypoint* level_kps, int capacity) {
+  DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   if (!counts) return fail(c, ORBX_ERR_INVALID_ARG, "counts is NULL");
   if (first < 0 || n < 1 || first + n > c->last_n) return fail(c, ORBX_ERR_INVALID_ARG, "frame range outside batch");
@@ -1045,6 +1076,7 @@ int orbx_detect_and_compute(orbx_ctx* c, const uint8_t* image, int width, int he
                             orbx_keypoint* keypoints, float* orientations, orbx_descriptor* descriptors,
                             float* responses, int32_t* levels, orbx_keypoint* level_kps, int capacity,
                             int* count) {
+  DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   if (!count) return fail(c, ORBX_ERR_INVALID_ARG, "count is NULL");
   int st = orbx_detect_and_compute_batch_host(c, image, 1, width, height, stride, (size_t)stride * height);
@@ -1057,12 +1089,13 @@ int orbx_detect_and_compute(orbx_ctx* c, const uint8_t* image, int width, int he
 }
 
 int orbx_bench_stage(orbx_ctx* c, int n_frames, int stage, int reps, float* avg_ms) {
+  DeviceGuard _dg(c);
   if (!c || !avg_ms) return ORBX_ERR_INVALID_ARG;
   if (c->plan_w == 0) return fail(c, ORBX_ERR_INVALID_ARG, "run a batch first (no pyramid built)");
   if (n_frames < 1 || n_frames > c->last_n || reps < 1) return fail(c, ORBX_ERR_INVALID_ARG, "n_frames/reps");
   const OrbxPlan& P = c->plan;
   hipStream_t s = c->stream;
-  OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2, fast_ablate()};
+  OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2};
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipEventRecord(c->ev[0], s));
   for (int i = 0; i < reps; i++) {
@@ -1095,6 +1128,7 @@ int orbx_bench_stage(orbx_ctx* c, int n_frames, int stage, int reps, float* avg_
 
 int orbx_fast_score(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, int threshold, int n,
                     float* scores) {
+  DeviceGuard _dg(c);
   int st = check_image(c, image, width, height, stride);
   if (st != ORBX_OK) return st;
   if (!scores || n < 1 || n > 16 || threshold < 0 || threshold > 255)
@@ -1114,7 +1148,7 @@ int orbx_fast_score(orbx_ctx* c, const uint8_t* image, int width, int height, in
   const size_t npx = (size_t)width * height;
   if ((st = ensure(c, c->s_u16, npx * 2)) != ORBX_OK) return st;
   if ((st = ensure(c, c->s_mask, (size_t)P.mask_words * 8)) != ORBX_OK) return st;
-  OrbxFastParams fp{threshold, n, 0, 0};
+  OrbxFastParams fp{threshold, n, 0};
   HIPCHK(c, orbx_launch_fast_nms(c->stream, (const OrbxTileDesc*)c->s_tiles.p, (int)t.size(), 1,
                                  (const uint8_t*)c->s_img_a.p, P.frame_bytes, P.mask_words, fp,
                                  (unsigned long long*)c->s_mask.p, (uint16_t*)c->s_u16.p, nullptr));
@@ -1145,6 +1179,7 @@ static int compact_and_fetch(orbx_ctx* c, const OrbxPlan& P, int nfeatures, orbx
 
 int orbx_fast(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, int threshold, int n,
               int nms_window, int nfeatures, orbx_keypoint* keypoints, int* count, int* total) {
+  DeviceGuard _dg(c);
   int st = check_image(c, image, width, height, stride);
   if (st != ORBX_OK) return st;
   if (!count || (!keypoints && nfeatures > 0) || nfeatures < 0 || n < 1 || n > 16 || threshold < 0 ||
@@ -1163,7 +1198,7 @@ int orbx_fast(orbx_ctx* c, const uint8_t* image, int width, int height, int stri
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->s_tiles.p, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
   if ((st = ensure(c, c->s_mask, (size_t)P.mask_words * 8)) != ORBX_OK) return st;
-  OrbxFastParams fp{threshold, n, nms_window / 2, 0};
+  OrbxFastParams fp{threshold, n, nms_window / 2};
   // stage operator: exact totals are part of the contract -> no early exit
   HIPCHK(c, orbx_launch_fast_nms(c->stream, (const OrbxTileDesc*)c->s_tiles.p, (int)t.size(), 1,
                                  (const uint8_t*)c->s_img_a.p, P.frame_bytes, P.mask_words, fp,
@@ -1173,6 +1208,7 @@ int orbx_fast(orbx_ctx* c, const uint8_t* image, int width, int height, int stri
 
 int orbx_nms(orbx_ctx* c, const float* scores, int width, int height, int nms_window, int nfeatures,
              float threshold, orbx_keypoint* keypoints, int* count, int* total) {
+  DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   if (!scores || !count || (!keypoints && nfeatures > 0) || nfeatures < 0 || width < 1 || height < 1 ||
       nms_window < 0 || nms_window / 2 > 3)
@@ -1227,12 +1263,14 @@ static int describe_stage(orbx_ctx* c, const uint8_t* image, int width, int heig
 
 int orbx_orientations(orbx_ctx* c, const uint8_t* image, int width, int height, int stride,
                       const orbx_keypoint* keypoints, int nkp, int patch_size, float* orientations) {
+  DeviceGuard _dg(c);
   if (c && nkp > 0 && !orientations) return fail(c, ORBX_ERR_INVALID_ARG, "orientations is NULL");
   return describe_stage(c, image, width, height, stride, keypoints, nkp, patch_size, nullptr, orientations, nullptr);
 }
 
 int orbx_brief(orbx_ctx* c, const uint8_t* image, int width, int height, int stride,
                const orbx_keypoint* keypoints, const float* orientations, int nkp, orbx_descriptor* descriptors) {
+  DeviceGuard _dg(c);
   if (c && nkp > 0 && (!orientations || !descriptors))
     return fail(c, ORBX_ERR_INVALID_ARG, "orientations/descriptors is NULL");
   return describe_stage(c, image, width, height, stride, keypoints, nkp, 31, orientations, nullptr, descriptors);
@@ -1240,6 +1278,7 @@ int orbx_brief(orbx_ctx* c, const uint8_t* image, int width, int height, int str
 
 int orbx_harris(orbx_ctx* c, const uint8_t* image, int width, int height, int stride,
                 const orbx_keypoint* keypoints, int nkp, int window, float k, float* responses) {
+  DeviceGuard _dg(c);
   int st = check_image(c, image, width, height, stride);
   if (st != ORBX_OK) return st;
   if (nkp < 0 || (nkp > 0 && (!keypoints || !responses)) || window < 1 || (window % 2) == 0 || window > 15)
@@ -1293,11 +1332,13 @@ static int blur_stage(orbx_ctx* c, const uint8_t* image, int width, int height, 
 
 int orbx_blur5_sep(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, uint8_t* dst,
                    int dst_stride) {
+  DeviceGuard _dg(c);
   return blur_stage(c, image, width, height, stride, dst, dst_stride, ORBX_BLUR_SEP16);
 }
 
 int orbx_blur5_273(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, uint8_t* dst,
                    int dst_stride) {
+  DeviceGuard _dg(c);
   return blur_stage(c, image, width, height, stride, dst, dst_stride, ORBX_BLUR_K273);
 }
 
@@ -1327,6 +1368,7 @@ static int conv_stage(orbx_ctx* c, const uint8_t* image, int width, int height, 
 
 int orbx_conv2d(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, const float* kernel,
                 int kernel_size, uint8_t* dst) {
+  DeviceGuard _dg(c);
   return conv_stage(c, image, width, height, stride, kernel, kernel_size, 0, dst);
 }
 
@@ -1336,6 +1378,7 @@ int orbx_gaussian_kernel(int kernel_size, float sigma, float* kernel) {
 
 int orbx_gaussian_blur_conv(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, int kernel_size,
                             uint8_t* dst) {
+  DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   if (kernel_size < 1 || (kernel_size % 2) == 0 || kernel_size > 31)
     return fail(c, ORBX_ERR_INVALID_ARG, "kernel_size must be odd and <= 31 (src/GaussianBlur.cpp:8-11)");
@@ -1345,6 +1388,7 @@ int orbx_gaussian_blur_conv(orbx_ctx* c, const uint8_t* image, int width, int he
 }
 
 int orbx_sobel(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, int dir, uint8_t* dst) {
+  DeviceGuard _dg(c);
   static const float SX[9] = {-1.f, 0.f, 1.f, -2.f, 0.f, 2.f, -1.f, 0.f, 1.f};   // src/Sobel.cpp:6-10
   static const float SY[9] = {-1.f, -2.f, -1.f, 0.f, 0.f, 0.f, 1.f, 2.f, 1.f};   // src/Sobel.cpp:12-16
   return conv_stage(c, image, width, height, stride, dir == 0 ? SX : SY, 3, 1, dst);
@@ -1352,6 +1396,7 @@ int orbx_sobel(orbx_ctx* c, const uint8_t* image, int width, int height, int str
 
 int orbx_build_pyramid_level(orbx_ctx* c, const uint8_t* image, int width, int height, int stride, int level,
                              uint8_t* dst, int* level_w, int* level_h) {
+  DeviceGuard _dg(c);
   int st = check_image(c, image, width, height, stride);
   if (st != ORBX_OK) return st;
   if (level < 0 || level >= c->p.nlevels || !dst) return fail(c, ORBX_ERR_INVALID_ARG, "level out of range / dst NULL");
@@ -1373,6 +1418,7 @@ int orbx_build_pyramid_level(orbx_ctx* c, const uint8_t* image, int width, int h
 }
 
 int orbx_select_top(orbx_ctx* c, const float* responses, int n, int keep, int32_t* indices, int* kept) {
+  DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   if (n < 0 || keep < 0 || (n > 0 && (!responses || !indices)) || !kept)
     return fail(c, ORBX_ERR_INVALID_ARG, "bad select_top arguments");
@@ -1442,6 +1488,7 @@ static int compact_matches(orbx_ctx* c, const int32_t* match, const int32_t* dis
 
 int orbx_knn2(orbx_ctx* c, const orbx_descriptor* query, int nq, const orbx_descriptor* train, int nt,
               int32_t* idx, int32_t* dist) {
+  DeviceGuard _dg(c);
   if (c && nq > 0 && (!idx || !dist)) return fail(c, ORBX_ERR_INVALID_ARG, "idx/dist is NULL");
   std::vector<int32_t> vi, vd, vm;
   int st = knn_host(c, query, nq, train, nt, 0.8, &vi, &vd, &vm);
@@ -1455,6 +1502,7 @@ int orbx_knn2(orbx_ctx* c, const orbx_descriptor* query, int nq, const orbx_desc
 
 int orbx_match_ratio(orbx_ctx* c, const orbx_descriptor* query, int nq, const orbx_descriptor* train, int nt,
                      double ratio, int32_t* query_idx, int32_t* train_idx, int32_t* dist1, int capacity, int* count) {
+  DeviceGuard _dg(c);
   if (c && (!count || capacity < 0 || (capacity > 0 && (!query_idx || !train_idx))))
     return fail(c, ORBX_ERR_INVALID_ARG, "bad match output arguments");
   std::vector<int32_t> vi, vd, vm;
@@ -1464,6 +1512,7 @@ int orbx_match_ratio(orbx_ctx* c, const orbx_descriptor* query, int nq, const or
 }
 
 int orbx_batch_match_consecutive(orbx_ctx* c, double ratio) {
+  DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   if (c->last_n < 2) return fail(c, ORBX_ERR_INVALID_ARG, "needs a batch of at least two frames");
   const int n = c->last_n, cap = c->plan.out_cap > 0 ? c->plan.out_cap : 1;
@@ -1485,6 +1534,7 @@ int orbx_batch_match_consecutive(orbx_ctx* c, double ratio) {
 
 int orbx_batch_match_fetch(orbx_ctx* c, int pair, int32_t* query_idx, int32_t* train_idx, int32_t* dist1,
                            int capacity, int* count) {
+  DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   if (!count || capacity < 0 || (capacity > 0 && (!query_idx || !train_idx)))
     return fail(c, ORBX_ERR_INVALID_ARG, "bad match output arguments");
@@ -1565,6 +1615,7 @@ extern "C" {
 int orbx_lk_track(orbx_ctx* c, const uint8_t* prev, int prev_stride, const uint8_t* next, int next_stride, int width,
                   int height, const float* prev_pts_xy, int n, float* next_pts_xy, uint8_t* status, float* err,
                   int win_size, int max_level, int max_iters, double epsilon) {
+  DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   if (!next || n < 0 || (n > 0 && (!prev_pts_xy || !next_pts_xy || !status)))
     return fail(c, ORBX_ERR_INVALID_ARG, "next image / point arrays are NULL");

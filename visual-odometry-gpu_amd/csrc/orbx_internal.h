@@ -90,7 +90,6 @@ struct OrbxResizeTap {
 
 struct OrbxFastParams {
   int32_t threshold, n, nms_radius;
-  int32_t ablate;  // timing diagnostics only (ORBX_FAST_ABLATE); 0 in production
 };
 
 // tile geometry of the FAST/NMS kernel

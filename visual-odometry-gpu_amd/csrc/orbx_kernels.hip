@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void k_fast_nms2(const OrbxTileDesc* __restric
   constexpr int NIT = (N_ITEMS + 255) / 256;
   static_assert(NIT * 4 <= 32, "candidate bits must fit one register");
   uint32_t cand_bits = 0;
-  if (!(fp.ablate & 2)) {
+  {
     const uint32_t t_hi = (uint32_t)thr * 0x00010001u;
     // the reference's else-if makes "darker" strict when threshold == 0
     const uint32_t t_lo = (uint32_t)(thr == 0 ? 1 : thr) * 0x00010001u;
@@ -717,7 +717,6 @@ __global__ __launch_bounds__(256) void k_fast_nms2(const OrbxTileDesc* __restric
         sy += 1;
       }
     }
-    if (fp.ablate & 1) cand_bits = 0;  // diagnostics: no candidates -> phases 3/4 are empty
   }
   const uint32_t my_cands = cand_bits;  // kept for the queue-less overflow path
   {
@@ -797,7 +796,7 @@ __global__ __launch_bounds__(256) void k_fast_nms2(const OrbxTileDesc* __restric
       }
     }
   };
-  if (!(fp.ablate & 4)) {
+  {
     for (int q = tid; q < nq; q += 256) nms_candidate(s_queue[q]);
     if (overflow)
       for (uint32_t b = my_cands; b; b &= b - 1) nms_candidate(bit_pos(__ffs(b) - 1));
