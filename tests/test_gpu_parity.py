@@ -413,11 +413,11 @@ def test_fast_tile_counts(pkg, kitti0, kitti1):
         c.set_fast_early_exit(False)
         c.batch_host(frames)
         w0, t0 = c.fast_tile_counts()
-        assert w0 == t0 and t0 == 8 * 403  # 403 64x64 tiles over the 8 levels of a 1241x376 frame
+        assert w0 == t0 and t0 == 8 * 239  # 239 tiles of 128x54 over the 8 levels of a 1241x376 frame
         c.set_fast_early_exit(True)
         c.batch_host(frames)
         w1, t1 = c.fast_tile_counts()
-        assert t1 == t0 and 8 * 94 <= w1 < t0  # at least tile row 0 of every level (94 tiles per frame)
+        assert t1 == t0 and 8 * 48 <= w1 < t0  # at least tile row 0 of every level (48 tiles per frame)
 
 
 def test_graph_and_plain_launch_paths_agree(pkg, kitti0, kitti1):

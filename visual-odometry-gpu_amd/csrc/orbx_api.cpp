@@ -232,12 +232,13 @@ void make_tilemap(const OrbxPlan& plan, int tw, int th, bool use_pitch, OrbxTile
 
 // band-major order of the FAST tiles (levels shrink with the level index, so the
 // levels that have a tile row b are always a prefix of the level list)
-int make_bandmap(const OrbxPlan& plan, OrbxBandMap* bm, std::string* why) {
+int make_bandmap(const OrbxPlan& plan, int nms_radius, OrbxBandMap* bm, std::string* why) {
   std::memset(bm, 0, sizeof(*bm));
+  const int tw = ORBX_FAST3_TW, th = orbx_fast3_tile_h(nms_radius);
   int nb = 0;
   for (int l = 0; l < plan.nlevels; l++) {
-    bm->tiles_x[l] = (plan.L[l].w + ORBX_FAST_TW - 1) / ORBX_FAST_TW;
-    bm->tiles_y[l] = (plan.L[l].h + ORBX_FAST_TH - 1) / ORBX_FAST_TH;
+    bm->tiles_x[l] = (plan.L[l].w + tw - 1) / tw;
+    bm->tiles_y[l] = (plan.L[l].h + th - 1) / th;
     bm->xprefix[l + 1] = bm->xprefix[l] + bm->tiles_x[l];
     if (l > 0 && bm->tiles_y[l] > bm->tiles_y[l - 1]) {
       *why = "pyramid levels must not grow with the level index";
@@ -489,7 +490,7 @@ int set_plan(orbx_ctx* c, int w, int h) {
                       hipMemcpyHostToDevice));
   c->plan = plan;
   make_tilemap(plan, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &c->tm_blur);
-  if ((st = make_bandmap(plan, &c->bm_fast, &why)) != ORBX_OK) return fail(c, st, why);
+  if ((st = make_bandmap(plan, c->p.nms_window / 2, &c->bm_fast, &why)) != ORBX_OK) return fail(c, st, why);
   {
     std::vector<OrbxTileDesc> t;
     build_frame_tiles(plan, ORBX_BLUR2_TW, 4 * orbx_blur2_rows_per_wave(), false, &t);
@@ -862,7 +863,7 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
   CREATE_CHK(hipMalloc((void**)&c->d_row_stat, B * ORBX_FAST_STAT_WORDS * 8));
   {
     OrbxBandMap bmm;
-    if ((st = make_bandmap(M, &bmm, &why)) != ORBX_OK) {
+    if ((st = make_bandmap(M, p->nms_window / 2, &bmm, &why)) != ORBX_OK) {
       orbx_destroy(c);
       return fail(nullptr, st, why);
     }
@@ -1139,7 +1140,7 @@ int orbx_fast_score(orbx_ctx* c, const uint8_t* image, int width, int height, in
   OrbxPlan P = flat_plan(width, height, 0);
   OrbxBandMap bm;
   std::string why;
-  if ((st = make_bandmap(P, &bm, &why)) != ORBX_OK) return fail(c, st, why);
+  if ((st = make_bandmap(P, 0, &bm, &why)) != ORBX_OK) return fail(c, st, why);
   std::vector<OrbxTileDesc> t;
   build_fast_tiles(P, bm, 0, 1, &t);
   if ((st = ensure(c, c->s_tiles, t.size() * sizeof(OrbxTileDesc))) != ORBX_OK) return st;
@@ -1191,7 +1192,7 @@ int orbx_fast(orbx_ctx* c, const uint8_t* image, int width, int height, int stri
   OrbxPlan P = flat_plan(width, height, nfeatures);
   OrbxBandMap bm;
   std::string why;
-  if ((st = make_bandmap(P, &bm, &why)) != ORBX_OK) return fail(c, st, why);
+  if ((st = make_bandmap(P, nms_window / 2, &bm, &why)) != ORBX_OK) return fail(c, st, why);
   std::vector<OrbxTileDesc> t;
   build_fast_tiles(P, bm, 0, 1, &t);
   if ((st = ensure(c, c->s_tiles, t.size() * sizeof(OrbxTileDesc))) != ORBX_OK) return st;

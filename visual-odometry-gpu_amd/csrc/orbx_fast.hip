@@ -1,0 +1,501 @@
+// orbx_fast.hip -- FAST-n segment test + score + (2R+1)^2 NMS, fused, gfx950 only.
+//   reference semantics: src/orb_cpu.cpp:23-134 (pre-test :39-58, arc test :61-89, score :91-99,
+//   NMS + row-major cap :105-134); replaces d_Fast (src/cuda/Fast.cu:30-209) + d_NMS
+//   (src/cuda/NMS.cu:21-128).
+//
+// The kernel is bound by VALU issue, not by memory (profiles/r01/pmc_sq.md), so the design is about
+// wave-instructions per pixel:
+//   phase 1  tile + halo -> LDS, row-coalesced 8-byte loads (zero outside the image).
+//   phase 2  4-point pre-test on EVERY pixel.  A thread owns one dword column (4 pixels) of the
+//            score region and walks K = 8 rows of it: each image row is unpacked ONCE into packed
+//            16-bit pairs (2 v_perm) and then serves as north row, centre row and south row of three
+//            different steps; the pre-test itself is a 8-op v_pk_min/max_u16 network per pixel pair
+//            (2nd smallest / 2nd largest of N,E,S,W) + 4 packed ops for both polarities.  The
+//            candidate flags of the 8 rows x 4 pixels end up in one register per thread.
+//   phase 3  the candidates (~6 % of the pixels) are compacted once per tile into an LDS queue and
+//            evaluated 64 per wave: one ring pixel per ds_read_u8, ONE v_cmp per ring pixel and
+//            polarity whose result is a 64-bit scalar lane mask -- the 9-contiguous-arc test then
+//            runs on the SCALAR unit (AND-doubling over the 16 masks), off the VALU; score =
+//            16 v_sad_u32.
+//   phase 4  NMS of the candidates that became corners against the dense LDS score tile.
+//   phase 5  survivor mask rows -> global, 8-byte stores; tile-row statistics for the early exit.
+// Early exit of tiles that cannot reach the first `cap` row-major survivors: unchanged from the
+// first-generation kernel (see the comment at the exit test).
+#include <hip/hip_runtime.h>
+
+#include "orbx_internal.h"
+#include "orbx_wave.h"
+
+namespace {
+
+// geometry of a tile (R = NMS radius)
+template <int R>
+struct F3 {
+  static constexpr int TW = ORBX_FAST3_TW;       // 128 output pixels = 2 mask words per row
+  static constexpr int NC = TW / 4 + 2;          // dword columns of the score region: x0-4 .. x0+TW+4
+  static constexpr int NSEG = 256 / NC;          // 7 row segments -> 238 walking threads
+  static constexpr int K = ORBX_FAST3_K;         // rows per walk
+  static constexpr int SC_ROWS = NSEG * K;       // score region rows: y0-R .. y0+TH+R
+  static constexpr int TH = SC_ROWS - 2 * R;     // output rows of a tile
+  static constexpr int IMG_PITCH = TW + 16;      // bytes: x0-8 .. x0+TW+8
+  static constexpr int IMG_DW = IMG_PITCH / 4;
+  static constexpr int IMG_ROWS = SC_ROWS + 6;   // y0-R-3 .. y0+TH+R+3
+  static constexpr int SC_PITCH = NC * 4;        // u16 elements
+  static constexpr int QCAP = 1024;              // candidate queue entries (more candidates: several passes)
+  static constexpr int MASK_DW = TW / 32;        // mask dwords per tile row
+};
+static_assert(F3<1>::NC == 34 && F3<1>::NSEG == 7 && F3<1>::K == 8, "walk mapping (tid / 34 by multiply-shift) assumes 34 x 7");
+static_assert(F3<0>::TH == orbx_fast3_tile_h(0) && F3<3>::TH == orbx_fast3_tile_h(3), "host tile tables use orbx_fast3_tile_h");
+
+// pre-test of the two pixels in the 16-bit lanes of `ip`: sign bit of a lane SET = not a candidate.
+//   brighter >= 3  <=>  2nd smallest of (N,E,S,W) >= Ip + t      (src/orb_cpu.cpp:52-53,57)
+//   darker   >= 3  <=>  2nd largest  of (N,E,S,W) <= Ip - t      (:54-55; with t == 0 the else-if
+//   makes "darker" strict: cp < Ip, ZT)
+template <bool ZT>
+__device__ __forceinline__ uint32_t f3_pretest(uint32_t ip, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t T) {
+  const uint32_t m1 = pk_min_u16(a, b), M1 = pk_max_u16(a, b);
+  const uint32_t m2 = pk_min_u16(c, d), M2 = pk_max_u16(c, d);
+  const uint32_t X = pk_max_u16(m1, m2), Y = pk_min_u16(M1, M2);
+  const uint32_t lo2 = pk_min_u16(X, Y), hi2 = pk_max_u16(X, Y);
+  const uint32_t br = pk_sub(lo2, ip);  // >= t  <=> at least 3 brighter
+  uint32_t dk = pk_sub(ip, hi2);        // >= t  <=> at least 3 darker
+  if (ZT) dk = pk_sub(dk, 0x00010001u);
+  const uint32_t r = pk_max_i16(br, dk);
+  return ZT ? r : pk_sub(r, T);
+}
+
+// the walk of one thread: candidate flags of K rows x 4 pixels, byte b = pixel b of the dword,
+// bit k = row k of the walk (before border masking).  p points at the dword LEFT of the thread's
+// column in the first image row of the walk (row seg*K of the LDS image = score row seg*K - 3).
+template <int R, bool ZT>
+__device__ __forceinline__ uint32_t f3_walk(const uint32_t* p, uint32_t T) {
+  typedef F3<R> G;
+  uint32_t E[G::K + 6], O[G::K + 6];
+  uint32_t acc = 0;  // bit SET = not a candidate
+#pragma unroll
+  for (int i = 0; i < G::K + 6; i++) {
+    const uint32_t c = p[i * G::IMG_DW + 1];
+    // even pixels (0,2) and odd pixels (1,3) of the dword as 16-bit lanes
+    E[i] = __builtin_amdgcn_perm(c, c, 0x0c020c00u);
+    O[i] = __builtin_amdgcn_perm(c, c, 0x0c030c01u);
+    if (i >= 6) {
+      const int j = i - 3;  // centre row of this step
+      const uint32_t Lw = p[j * G::IMG_DW], Cw = p[j * G::IMG_DW + 1], Rw = p[j * G::IMG_DW + 2];
+      // perm: bytes 0-3 = 2nd argument, 4-7 = 1st
+      // east = x+3: px0 -> C.b3, px1 -> R.b0, px2 -> R.b1, px3 -> R.b2
+      const uint32_t ee = __builtin_amdgcn_perm(Rw, Cw, 0x0c050c03u), eo = __builtin_amdgcn_perm(Rw, Cw, 0x0c060c04u);
+      // west = x-3: px0 -> L.b1, px1 -> L.b2, px2 -> L.b3, px3 -> C.b0
+      const uint32_t we = __builtin_amdgcn_perm(Cw, Lw, 0x0c030c01u), wo = __builtin_amdgcn_perm(Cw, Lw, 0x0c040c02u);
+      const uint32_t ze = f3_pretest<ZT>(E[j], E[j - 3], ee, E[j + 3], we, T);
+      const uint32_t zo = f3_pretest<ZT>(O[j], O[j - 3], eo, O[j + 3], wo, T);
+      // the four sign bytes (px0..px3) side by side; row k ends up in bit k of every byte
+      const uint32_t F = __builtin_amdgcn_perm(zo, ze, 0x07030501u);
+      acc = (F & 0x80808080u) | (acc >> 1);
+    }
+  }
+  return ~acc;
+}
+
+// exists i: ring pixels i .. i+NARC-1 all pass, on the circular 16-ring (src/orb_cpu.cpp:71-89).
+// m[k] is the 64-bit LANE MASK of ring pixel k (one v_cmp each), so everything here is scalar
+// work (s_and_b64 / s_or_b64): AND-doubling, then an OR tree.  Bit l of the result = lane l.
+template <int NARC>
+__device__ __forceinline__ u64 f3_has_arc(const u64 (&m)[16]) {
+  u64 a[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) a[i] = m[i];
+  int len = 1;
+#pragma unroll
+  for (int step = 0; step < 4; step++) {
+    if (2 * len <= NARC) {
+      u64 b[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) b[i] = a[i] & a[(i + len) & 15];
+#pragma unroll
+      for (int i = 0; i < 16; i++) a[i] = b[i];
+      len *= 2;
+    }
+  }
+  if (len < NARC) {  // overlapping windows: AND is idempotent
+    u64 b[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) b[i] = a[i] & a[(i + NARC - len) & 15];
+#pragma unroll
+    for (int i = 0; i < 16; i++) a[i] = b[i];
+  }
+  u64 any = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) any |= a[i];
+  return any;
+}
+
+// run of >= n set bits in the circular 16-bit mask (any n; per-lane arithmetic)
+__device__ __forceinline__ bool f3_has_run16(uint32_t m, int n) {
+  const uint32_t x = m | (m << 16);
+  uint32_t acc = x;
+  int k = 1;
+  while (2 * k <= n) {
+    acc &= acc >> k;
+    k *= 2;
+  }
+  if (k < n) acc &= acc >> (n - k);
+  return (acc & 0xffffu) != 0;
+}
+
+// byte offsets of the 16 ring pixels (circle_offsets, src/orb_cpu.cpp:8-13) from pixel (x-3, y-3)
+template <int PITCH>
+struct F3Ring {
+  static constexpr int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+  static constexpr int dy[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
+  static constexpr int off(int k) { return (dy[k] + 3) * PITCH + dx[k] + 3; }
+};
+
+// queue entry (walking thread, flag index) -> score-region row / column
+__device__ __forceinline__ void f3_decode(uint32_t e, int K, int& sr, int& sc) {
+  const uint32_t t = e >> 5, bi = e & 31u;
+  const uint32_t seg = (t * 241u) >> 13;  // t / 34 for t < 256
+  const uint32_t col = t - seg * 34u;
+  sr = (int)(seg * (uint32_t)K + (bi & 7u));
+  sc = (int)(col * 4u + (bi >> 3));
+}
+
+// full segment test + score of one candidate per lane (src/orb_cpu.cpp:61-101).
+// NARC > 0: arc length known at compile time, scalar arc test; NARC == 0: any n, per-lane masks.
+template <int R, int NARC>
+__device__ __forceinline__ void f3_eval(const uint8_t* s_img, uint16_t* s_score, uint16_t* s_queue, int nq, int thr,
+                                        int n, int tid) {
+  typedef F3<R> G;
+  typedef F3Ring<G::IMG_PITCH> RG;
+  for (int q0 = (tid & ~63); q0 < nq; q0 += 256) {  // wave-uniform
+    const int q = q0 + (tid & 63);
+    const bool active = q < nq;
+    const uint32_t e = active ? s_queue[q] : 0u;
+    int sr, sc;
+    f3_decode(e, G::K, sr, sc);
+    const int pos = sr * G::SC_PITCH + sc;
+    if (active) s_queue[q] = (uint16_t)pos;  // the NMS pass reads positions
+    const uint8_t* p0 = s_img + sr * G::IMG_PITCH + sc + 1;  // pixel (x-3, y-3)
+    const int Ip = p0[3 * G::IMG_PITCH + 3];
+    int v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = p0[RG::off(k)];
+    const int hi = Ip + thr, lo = Ip - thr;
+    bool corner;
+    if (NARC > 0) {
+      u64 bm[16], dm[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) bm[k] = __builtin_amdgcn_ballot_w64(v[k] >= hi);
+      const u64 cb = f3_has_arc<NARC>(bm);
+#pragma unroll
+      for (int k = 0; k < 16; k++) dm[k] = __builtin_amdgcn_ballot_w64(v[k] <= lo);
+      corner = __builtin_amdgcn_inverse_ballot_w64(cb | f3_has_arc<NARC>(dm));
+    } else {
+      uint32_t nb = 0, nd = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        nb = __builtin_amdgcn_alignbit(nb, (uint32_t)(v[k] - hi), 31);  // bit = v < hi
+        nd = __builtin_amdgcn_alignbit(nd, (uint32_t)(lo - v[k]), 31);  // bit = v > lo
+      }
+      corner = f3_has_run16(~nb & 0xffffu, n) || f3_has_run16(~nd & 0xffffu, n);
+    }
+    uint32_t score = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) score = __builtin_amdgcn_sad_u16((uint32_t)Ip, (uint32_t)v[k], score);
+    if (active && corner) s_score[pos] = (uint16_t)score;
+  }
+}
+
+// NMS of the candidates that became corners (ties survive, src/orb_cpu.cpp:110-133); survivors of
+// the tile interior set their bit in the LDS mask
+template <int R>
+__device__ __forceinline__ void f3_nms(const uint16_t* s_score, const uint16_t* s_queue, int nq, uint32_t* s_mask32,
+                                       int tid) {
+  typedef F3<R> G;
+  for (int q0 = (tid & ~63); q0 < nq; q0 += 256) {
+    const int q = q0 + (tid & 63);
+    if (q < nq) {
+      const int pos = s_queue[q];
+      const int s = s_score[pos];
+      const int sr = pos / G::SC_PITCH, sc = pos - sr * G::SC_PITCH;
+      const int iy = sr - R, ix = sc - 4;
+      bool keep = s > 0 && iy >= 0 && iy < G::TH && ix >= 0 && ix < G::TW;
+#pragma unroll
+      for (int dy = -R; dy <= R; dy++)
+#pragma unroll
+        for (int dx = -R; dx <= R; dx++)
+          if (dy != 0 || dx != 0) keep = keep & !(s_score[pos + dy * G::SC_PITCH + dx] > s);
+      if (keep) atomicOr(&s_mask32[iy * G::MASK_DW + (ix >> 5)], 1u << (ix & 31));
+    }
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_fast3(const OrbxTileDesc* __restrict__ tiles, const uint8_t* __restrict__ pyr,
+                                               int frame_bytes, int mask_words, OrbxFastParams fp,
+                                               u64* __restrict__ mask, uint16_t* __restrict__ scores_out,
+                                               u64* __restrict__ row_stat) {
+  typedef F3<R> G;
+  __shared__ __attribute__((aligned(16))) uint32_t s_img32[G::IMG_ROWS * G::IMG_DW];
+  __shared__ __attribute__((aligned(16))) uint16_t s_score[(G::SC_ROWS + 2 * R) * G::SC_PITCH + 16];
+  __shared__ uint16_t s_queue[G::QCAP];
+  __shared__ __attribute__((aligned(8))) uint32_t s_mask32[G::TH * G::MASK_DW];
+  __shared__ int s_qn;
+  __shared__ int s_wtot[4];
+  __shared__ int s_skip;
+  __shared__ int s_surv;
+  // NMS reads (2R+1)^2 neighbourhoods of score rows 0 .. SC_ROWS-1: R guard rows above and below
+  uint16_t* const score0 = s_score + R * G::SC_PITCH + 8;
+
+  // everything about this tile in one 64-byte scalar load.  grid = (frames, tiles of one frame in
+  // band-major order): x is the fastest dispatch index, so tile row b of every frame is dispatched
+  // before tile row b+1 of any frame, and the table is shared by all frames (scalar cache).
+  const int f = blockIdx.x;
+  const OrbxTileDesc d = tiles[blockIdx.y];
+  const int w = d.w, h = d.h, pitch = d.pitch, cap = d.u0, mask_wpr = d.u1, tiles_x = d.u2;
+  const int tx = d.tx, ty = d.ty;
+  const uint8_t* img = pyr + ((size_t)f * (size_t)frame_bytes + d.img_off);
+  const int tid = threadIdx.x;
+  const int thr = fp.threshold;
+  const int x0 = tx * G::TW, y0 = ty * G::TH;
+  u64* mrow = mask + ((size_t)f * (size_t)mask_words + d.mask_off);
+  // per frame: ORBX_MAX_LEVELS x ORBX_MAX_BANDS tile-row statistics, then one "dead from tile row"
+  // word per level
+  u64* fstat = row_stat ? row_stat + (size_t)f * ORBX_FAST_STAT_WORDS : nullptr;
+  u64* stat = fstat ? fstat + d.stat_index : nullptr;
+  u64* dead_from = fstat ? fstat + ORBX_MAX_LEVELS * ORBX_MAX_BANDS + d.l : nullptr;
+
+  // Early exit.  Keypoints are kept in ROW-MAJOR order up to `cap` (src/orb_cpu.cpp:108-110,
+  // src/orb.cpp:63), so once the tile rows strictly above this one are complete and already hold
+  // >= cap survivors, nothing in this tile can be among the first cap.  Such a tile stores nothing:
+  // its mask words are never looked at (the row-major walk of the selection kernel ignores
+  // everything after the first cap survivors).  The test reads completed statistics only, so it
+  // never depends on dispatch order (a stale read just means "do the work"); the first tile that
+  // proves row b dead publishes 64-b in dead_from (monotone max) so that later tiles decide with one load.
+  if (stat && ty > 0) {
+    if (tid < 64) {
+      u64 st = 0;
+      if (tid < ty) st = __hip_atomic_load(&stat[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 63) st = __hip_atomic_load(dead_from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int known = (int)__builtin_amdgcn_readlane((uint32_t)st, 63);  // 64 - (first dead row), 0: unknown
+      bool skip = known >= 64 - ty;
+      if (!skip) {
+        const bool complete = tid >= ty || (int)(st >> 32) == tiles_x;
+        const u64 inc = __ballot(!complete);                   // rows not yet complete
+        const int k = inc ? __ffsll((long long)inc) - 1 : 64;  // first incomplete row
+        const int surv = wave_sum(tid < k && tid < ty ? (int)(uint32_t)st : 0);
+        skip = surv >= cap;
+        if (skip && tid == 0)
+          __hip_atomic_fetch_max(dead_from, (u64)(64 - ty), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (tid == 0) s_skip = skip;
+    }
+    __syncthreads();
+    if (s_skip) return;
+  }
+
+  // ---- phase 1: tile + halo -> LDS (8-byte loads; x0-8 is 8-byte aligned, pitch a multiple of 64)
+  {
+    constexpr int CPR = G::IMG_PITCH / 8;  // 18 loads per row
+    constexpr int RPP = 256 / CPR;         // 14 rows per pass
+    constexpr int NP = (G::IMG_ROWS + RPP - 1) / RPP;
+    const int r0 = (tid * 3641) >> 16;     // tid / 18
+    const int c = tid - r0 * CPR;
+    const int gx = x0 - 8 + 8 * c;
+    const bool xok = (unsigned)gx < (unsigned)pitch && r0 < RPP;
+    const int gy0 = y0 - R - 3 + r0;
+    uint2 v[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      const int gy = gy0 + RPP * k;
+      v[k] = make_uint2(0u, 0u);
+      if (xok && (unsigned)gy < (unsigned)h && r0 + RPP * k < G::IMG_ROWS)
+        v[k] = *reinterpret_cast<const uint2*>(img + (uint32_t)(gy * pitch + gx));
+    }
+    // zero the score tile (and its guard rows) and the survivor mask while the loads are in flight
+    {
+      constexpr int NZ = (int)(sizeof(s_score) / 16);
+      for (int i = tid; i < NZ; i += 256) reinterpret_cast<uint4*>(s_score)[i] = make_uint4(0u, 0u, 0u, 0u);
+      for (int i = tid; i < G::TH * G::MASK_DW; i += 256) s_mask32[i] = 0u;
+      if (tid == 0) {
+        s_qn = 0;
+        s_surv = 0;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NP; k++)
+      if (r0 < RPP && r0 + RPP * k < G::IMG_ROWS)
+        reinterpret_cast<uint2*>(s_img32)[(r0 + RPP * k) * CPR + c] = v[k];
+  }
+  __syncthreads();
+
+  // ---- phase 2: pre-test walk (src/orb_cpu.cpp:39-58)
+  uint32_t cand = 0;
+  {
+    const int seg = (tid * 241) >> 13;  // tid / 34
+    const int col = tid - seg * G::NC;
+    const int gy_first = y0 - R + seg * G::K;  // image row of walk row 0
+    // rows that can hold a corner: 3 <= gy < h-3 (src/orb_cpu.cpp:35); a wave whose rows all lie
+    // outside skips the walk
+    if (seg < G::NSEG && gy_first < h - 3 && gy_first + G::K > 3) {
+      const uint32_t* p = s_img32 + (seg * G::K) * G::IMG_DW + col;
+      const uint32_t T = (uint32_t)thr * 0x00010001u;
+      cand = thr == 0 ? f3_walk<R, true>(p, T) : f3_walk<R, false>(p, T);
+      // pixels that can hold a corner and that this tile needs: 3 <= gx < w-3, x0-R <= gx < x0+TW+R
+      const int gx = x0 - 4 + 4 * col;
+      const int lo_x = max(max(3, x0 - R) - gx, 0), hi_x = min(min(w - 3, x0 + G::TW + R) - gx, 4);
+      const uint32_t cm = hi_x > lo_x ? ((0xffffffffu >> (32 - 8 * hi_x)) & ~((1u << (8 * lo_x)) - 1u)) : 0u;
+      const int lo_y = max(3 - gy_first, 0), hi_y = min(h - 3 - gy_first, G::K);
+      const uint32_t rm = hi_y > lo_y ? (((1u << hi_y) - 1u) & ~((1u << lo_y) - 1u)) * 0x01010101u : 0u;
+      cand &= cm & rm;
+    }
+  }
+  // compaction of the candidate flags into the LDS queue, once per tile: wave prefix sum of the
+  // popcounts + one LDS atomic per wave.  A queue entry = (walking thread, flag index).
+  const uint32_t my_cands = cand;
+  const uint32_t ebase = (uint32_t)tid << 5;
+  const int cnt = __popc(cand);
+  const int incl = wave_scan_incl(cnt);
+  const int wtotal = __builtin_amdgcn_readlane(incl, 63);
+  {
+    int wbase = 0;
+    if ((tid & 63) == 63) {
+      wbase = atomicAdd(&s_qn, incl);
+      s_wtot[tid >> 6] = incl;
+    }
+    wbase = __builtin_amdgcn_readlane(wbase, 63);
+    int pos = wbase + incl - cnt;
+    while (cand) {
+      const int bpos = __ffs(cand) - 1;
+      cand &= cand - 1;
+      if (pos < G::QCAP) s_queue[pos] = (uint16_t)(ebase | (uint32_t)bpos);
+      pos++;
+    }
+  }
+  (void)wtotal;
+  __syncthreads();
+
+  const uint8_t* s_img = reinterpret_cast<const uint8_t*>(s_img32);
+  const int ntot = s_qn;
+  const int n = fp.n;
+  auto eval = [&](int nq) {
+    if (n == 9)
+      f3_eval<R, 9>(s_img, score0, s_queue, nq, thr, n, tid);
+    else if (n == 12)
+      f3_eval<R, 12>(s_img, score0, s_queue, nq, thr, n, tid);
+    else
+      f3_eval<R, 0>(s_img, score0, s_queue, nq, thr, n, tid);
+  };
+  if (ntot <= G::QCAP) {  // block-uniform
+    // ---- phase 3: full segment test + score of the candidates
+    eval(ntot);
+    __syncthreads();
+    // ---- phase 4: NMS
+    f3_nms<R>(score0, s_queue, ntot, s_mask32, tid);
+  } else {
+    // more candidates than the queue holds (noise, tiny thresholds): windows of QCAP candidates in
+    // a fixed order (wave bases from the per-wave totals, not from the atomic)
+    int wbase = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (k < (tid >> 6)) wbase += s_wtot[k];
+    const int first = wbase + incl - cnt;
+    auto fill_window = [&](int base) {
+      int pos = first - base;
+      for (uint32_t b = my_cands; b; b &= b - 1) {
+        if (pos >= 0 && pos < G::QCAP) s_queue[pos] = (uint16_t)(ebase | (uint32_t)(__ffs(b) - 1));
+        pos++;
+      }
+    };
+    for (int base = 0; base < ntot; base += G::QCAP) {
+      __syncthreads();
+      fill_window(base);
+      __syncthreads();
+      eval(min(G::QCAP, ntot - base));
+    }
+    for (int base = 0; base < ntot; base += G::QCAP) {
+      __syncthreads();
+      fill_window(base);
+      __syncthreads();
+      // (entries are (thread, flag) again: positions are recomputed)
+      const int nq = min(G::QCAP, ntot - base);
+      for (int q = tid; q < nq; q += 256) {
+        int sr, sc;
+        f3_decode(s_queue[q], G::K, sr, sc);
+        s_queue[q] = (uint16_t)(sr * G::SC_PITCH + sc);
+      }
+      __syncthreads();
+      f3_nms<R>(score0, s_queue, nq, s_mask32, tid);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 5: one 8-byte store per mask word of the tile; the tile's survivor count joins the
+  // tile-row statistics
+  {
+    constexpr int WPR = G::TW / 64;  // mask words per tile row
+    int surv = 0;
+    if (tid < G::TH * WPR) {
+      const int iy = tid / WPR, wj = tid - iy * WPR;
+      const int gy = y0 + iy, gw = tx * WPR + wj;
+      const u64 word = reinterpret_cast<const u64*>(s_mask32)[tid];
+      if (gy < h && gw < mask_wpr) {
+        mrow[(size_t)gy * mask_wpr + gw] = word;
+        surv = __popcll(word);
+      }
+    }
+    if (stat) {
+      static_assert(G::TH * WPR <= 128, "survivor count: two waves");
+      if (tid < 128) {
+        const int ws = wave_sum(surv);
+        if ((tid & 63) == 0) atomicAdd(&s_surv, ws);
+      }
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_fetch_add(&stat[ty], (1ull << 32) | (u64)(uint32_t)s_surv, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (scores_out) {  // stage operator Fast()/orbx_fast_score: the dense score map
+    for (int i = tid; i < G::TH * G::TW; i += 256) {
+      const int iy = i / G::TW, ix = i - iy * G::TW;
+      const int gy = y0 + iy, gx = x0 + ix;
+      if (gy < h && gx < w) scores_out[(size_t)gy * w + gx] = score0[(iy + R) * G::SC_PITCH + ix + 4];
+    }
+  }
+}
+
+template <int R>
+void launch_fast3(dim3 grid, hipStream_t s, const OrbxTileDesc* d_tiles, const uint8_t* d_pyr, int frame_bytes,
+                  int mask_words, OrbxFastParams fp, unsigned long long* d_mask, uint16_t* d_scores,
+                  unsigned long long* d_row_stat) {
+  hipLaunchKernelGGL((k_fast3<R>), grid, dim3(256), 0, s, d_tiles, d_pyr, frame_bytes, mask_words, fp, d_mask,
+                     d_scores, d_row_stat);
+}
+
+}  // namespace
+
+// d_tiles: the n_tiles tiles of ONE frame in band-major order (tile = ORBX_FAST3_TW x
+// orbx_fast3_tile_h(nms_radius)); grid = (frames, tiles).
+// d_row_stat: n_frames * ORBX_FAST_STAT_WORDS zeroed u64 (or NULL: no early exit)
+hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int n_frames,
+                                const uint8_t* d_pyr, int frame_bytes, int mask_words, OrbxFastParams fp,
+                                unsigned long long* d_mask, uint16_t* d_scores, unsigned long long* d_row_stat) {
+  if (n_tiles <= 0 || n_frames <= 0) return hipSuccess;
+  if (n_tiles > 65535) return hipErrorInvalidValue;
+  dim3 grid(n_frames, n_tiles);
+  switch (fp.nms_radius) {
+    case 0:
+      launch_fast3<0>(grid, s, d_tiles, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores, d_row_stat);
+      break;
+    case 1:
+      launch_fast3<1>(grid, s, d_tiles, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores, d_row_stat);
+      break;
+    case 2:
+      launch_fast3<2>(grid, s, d_tiles, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores, d_row_stat);
+      break;
+    default:
+      launch_fast3<3>(grid, s, d_tiles, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores, d_row_stat);
+      break;
+  }
+  return hipGetLastError();
+}

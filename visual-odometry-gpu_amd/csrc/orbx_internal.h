@@ -92,9 +92,14 @@ struct OrbxFastParams {
   int32_t threshold, n, nms_radius;
 };
 
-// tile geometry of the FAST/NMS kernel
-#define ORBX_FAST_TW 64
-#define ORBX_FAST_TH 64
+// tile geometry of the FAST/NMS kernel (orbx_fast.hip): 128 output pixels wide (two mask words per
+// row); 34 dword columns x 7 row segments of walking threads, 8 rows per walk, so the score region
+// of a tile has 56 rows and a tile 56 - 2 * nms_radius output rows
+#define ORBX_FAST3_TW 128
+#define ORBX_FAST3_K 8
+constexpr int orbx_fast3_tile_h(int nms_radius) {
+  return (256 / (ORBX_FAST3_TW / 4 + 2)) * ORBX_FAST3_K - 2 * nms_radius;
+}
 // tile geometry of the blur kernel
 #define ORBX_BLUR_TW 64
 #define ORBX_BLUR_TH 16
@@ -139,10 +144,11 @@ hipError_t orbx_launch_blur(hipStream_t s, const OrbxPlan& plan, const OrbxTileM
 // d_tiles: tiles of ONE frame for 248 x (4*rows_per_wave) strips
 hipError_t orbx_launch_blur2(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int n_frames,
                              const uint8_t* d_src, uint8_t* d_dst, int first_level);
-// d_tiles: n_tiles OrbxTileDesc in band-major order (orbx_api.cpp: build_fast_tiles)
+// d_tiles: n_tiles OrbxTileDesc in band-major order (orbx_api.cpp: build_fast_tiles, tile height
+// orbx_fast3_tile_h(fp.nms_radius)); d_scores: optional dense u16 score map of ONE frame (stage operator)
 hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int n_frames,
                                 const uint8_t* d_pyr, int frame_bytes, int mask_words, OrbxFastParams fp,
-                                unsigned long long* d_mask, uint16_t* d_scores_dbg,
+                                unsigned long long* d_mask, uint16_t* d_scores,
                                 unsigned long long* d_row_stat);
 hipError_t orbx_launch_compact(hipStream_t s, const OrbxPlan& plan, int n_frames,
                                const unsigned long long* d_mask, orbx_keypoint* d_cand, int32_t* d_cand_count,

@@ -24,9 +24,7 @@
 
 #include "orbx_internal.h"
 #include "orbx_math.h"
-
-typedef unsigned long long u64;
-typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+#include "orbx_wave.h"
 
 __constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 #include "pattern_31.inc"
@@ -36,8 +34,6 @@ __constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 // helpers
 
 typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // (level, tile_x, tile_y) of this workgroup
 __device__ __forceinline__ void decode_tile(const OrbxTileMap& tm, int nlevels, int& l, int& tx, int& ty) {
@@ -58,32 +54,6 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   if (p >= len) p = 2 * len - p - 2;
   p = p < 0 ? 0 : p;
   return p >= len ? len - 1 : p;
-}
-
-// wave-wide integer sum, result in every lane.  DPP within the 16-lane rows
-// (no LDS-crossbar round trips), then the four row sums are combined on the SALU.
-__device__ __forceinline__ int wave_sum(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x4E /*quad_perm:[2,3,0,1]*/, 0xf, 0xf, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x141 /*row_half_mirror*/, 0xf, 0xf, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x140 /*row_mirror*/, 0xf, 0xf, true);
-  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
-         __builtin_amdgcn_readlane(v, 48);
-}
-
-// wave-wide inclusive prefix sum (lane i gets v_0 + ... + v_i) with DPP only
-// (GCN cross-lane scan: row_shr 1/2/3, row_shr 4 and 8 with bank masks, then
-// row_bcast 15 / 31 across the 16-lane rows)
-__device__ __forceinline__ int wave_scan_incl(int v) {
-  const int v0 = v;
-  v += __builtin_amdgcn_update_dpp(0, v0, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v0, 0x112 /*row_shr:2*/, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v0, 0x113 /*row_shr:3*/, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114 /*row_shr:4*/, 0xf, 0xe, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118 /*row_shr:8*/, 0xf, 0xc, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142 /*row_bcast:15*/, 0xa, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x143 /*row_bcast:31*/, 0xc, 0xf, false);
-  return v;
 }
 
 // ---------------------------------------------------------------------------
@@ -361,12 +331,6 @@ __global__ __launch_bounds__(256) void k_blur(OrbxPlan plan, OrbxTileMap tm, con
 //   image's last pixel (and the virtual dword left of x = 0) with v_perm.
 #define BL2_TW 248   // productive pixels per wave row: lanes 1..62 (lanes 0 and 63 are halo-only)
 
-__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) + __builtin_bit_cast(us2_t, b)));
-}
-__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) - __builtin_bit_cast(us2_t, b)));
-}
 __device__ __forceinline__ uint32_t pk_mad(uint32_t a, unsigned short m, uint32_t c) {
   const us2_t mm = {m, m};
   return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) * mm + __builtin_bit_cast(us2_t, c)));
@@ -513,319 +477,7 @@ __global__ __launch_bounds__(256) void k_blur2(const OrbxTileDesc* __restrict__ 
     blur2_rows<RH, false>(Craw, selL, selC, selR, vmask, rout, voff_st, ya, h, pitch);
 }
 
-// ---------------------------------------------------------------------------
-// 3. FAST-n segment test + score + (2R+1)^2 NMS, fused, one 64x64 tile (+halo)
-//    per workgroup (src/orb_cpu.cpp:23-134; src/cuda/Fast.cu:30-209,
-//    src/cuda/NMS.cu:21-128).
-//    phase 1  row-coalesced 8-byte loads of tile+halo into LDS
-//    phase 2  4-point pre-test on every pixel, 4 pixels per lane (below)
-//    phase 3  dense full segment test + score on the compacted candidates
-//    phase 4  NMS for corners only; survivors set bits in an LDS mask
-//    phase 5  one 8-byte store per tile row of the survivor mask
-__device__ __forceinline__ bool has_run16(uint32_t m, int n) {
-  uint32_t x = m | (m << 16);
-  uint32_t acc = x;
-  int k = 1;
-  while (2 * k <= n) {
-    acc &= acc >> k;
-    k *= 2;
-  }
-  if (k < n) acc &= acc >> (n - k);
-  return (acc & 0xffffu) != 0;
-}
-
-// Workgroup order (the tile table built by the host) is BAND-MAJOR: all tiles of
-// tile-row 0 of every level of every frame come first, then tile-row 1, ...  Together
-// with the per-(frame, level, tile-row) statistics below this lets a tile
-// prove that it cannot contribute: keypoints are kept in ROW-MAJOR order up
-// to `cap` (src/orb_cpu.cpp:108-110, src/orb.cpp:63), so once the tile rows
-// strictly above a tile are complete and already hold >= cap survivors,
-// nothing in this tile can be among the first cap.  Such tiles write an empty
-// mask and exit.  The test only ever reads completed statistics, so it is
-// independent of dispatch order (a stale read just means "do the work").
-static_assert(ORBX_FAST_TH == 64, "phase 5 assumes one wave per tile column of mask words");
-#define F2_IMG_PITCH 80                 // bytes: x0-8 .. x0+71
-#define F2_IMG_DW (F2_IMG_PITCH / 4)    // 20
-#define F2_SC_PITCH 72                  // score tile columns: x0-4 .. x0+67
-#define F2_DCOLS (F2_SC_PITCH / 4)      // 18 dword columns per score row
-// candidate queue capacity.  A tile has up to 72*70 candidates but natural images give
-// ~300; a bounded queue keeps LDS at 20 KB (8 workgroups per CU).  Tiles with more
-// candidates (noise, tiny thresholds) take a slower, queue-less path.
-#define F2_QCAP 2048
-
-// pre-test of the two pixels held in the 16-bit lanes of the arguments;
-// returns bit15 / bit31 set for candidates
-__device__ __forceinline__ uint32_t pretest_pk(uint32_t ip, uint32_t a, uint32_t b, uint32_t c, uint32_t d,
-                                               uint32_t t_hi, uint32_t t_lo) {
-  const us2_t A = __builtin_bit_cast(us2_t, a), B = __builtin_bit_cast(us2_t, b);
-  const us2_t C = __builtin_bit_cast(us2_t, c), D = __builtin_bit_cast(us2_t, d);
-  const us2_t I = __builtin_bit_cast(us2_t, ip);
-  const us2_t TH = __builtin_bit_cast(us2_t, t_hi), TL = __builtin_bit_cast(us2_t, t_lo);
-  const us2_t m1 = __builtin_elementwise_min(A, B), M1 = __builtin_elementwise_max(A, B);
-  const us2_t m2 = __builtin_elementwise_min(C, D), M2 = __builtin_elementwise_max(C, D);
-  const us2_t X = __builtin_elementwise_max(m1, m2), Y = __builtin_elementwise_min(M1, M2);
-  const us2_t lo2 = __builtin_elementwise_min(X, Y), hi2 = __builtin_elementwise_max(X, Y);
-  const us2_t d1 = lo2 - (I + TH);  // >= 0 (as int16) <=> at least 3 brighter
-  const us2_t d2 = (I - TL) - hi2;  // >= 0 (as int16) <=> at least 3 darker
-  return ~(__builtin_bit_cast(uint32_t, d1) & __builtin_bit_cast(uint32_t, d2)) & 0x80008000u;
-}
-
-template <int R, bool WRITE_SCORES>
-__global__ __launch_bounds__(256) void k_fast_nms2(const OrbxTileDesc* __restrict__ tiles,
-                                                   const uint8_t* __restrict__ pyr, int frame_bytes,
-                                                   int mask_words, OrbxFastParams fp,
-                                                   u64* __restrict__ mask, uint16_t* __restrict__ scores_dbg,
-                                                   u64* __restrict__ row_stat) {
-  constexpr int TH = ORBX_FAST_TH, TW = ORBX_FAST_TW;
-  constexpr int IMG_ROWS = TH + 6 + 2 * R;
-  constexpr int SC_ROWS = TH + 2 * R;
-  constexpr int N_ITEMS = SC_ROWS * F2_DCOLS;
-  __shared__ __attribute__((aligned(16))) uint32_t s_img32[IMG_ROWS * F2_IMG_DW];
-  __shared__ __attribute__((aligned(16))) uint16_t s_score[SC_ROWS * F2_SC_PITCH];
-  __shared__ uint16_t s_queue[F2_QCAP];
-  __shared__ __attribute__((aligned(8))) uint32_t s_mask32[TH * 2];
-  __shared__ int s_qn;
-  __shared__ int s_skip;
-
-  // everything about this tile in one 64-byte scalar load.  grid = (frames, tiles of
-  // one frame in band-major order): x is the fastest dispatch index, so band b of
-  // every frame is dispatched before band b+1 of any frame, and the 25 KB table is
-  // shared by all frames (it stays in the scalar cache).
-  const int f = blockIdx.x;
-  const OrbxTileDesc d = tiles[blockIdx.y];
-  struct {
-    int w, h, pitch, cap, mask_wpr;
-  } L = {d.w, d.h, d.pitch, d.u0, d.u1};
-  // the workgroup owns the tiles tx_first .. tx_first + n_strip - 1 of tile row ty.  The
-  // production table gives every workgroup ONE tile: strips of several tiles were measured
-  // slower (their later tile rows start before the row above is complete)
-  const int tx_first = d.tx, ty = d.ty, tiles_x = d.u2, n_strip = d.f;
-  const uint8_t* img = pyr + ((size_t)f * (size_t)frame_bytes + d.img_off);
-  const int tid = threadIdx.x;
-  const int thr = fp.threshold;
-  const int y0 = ty * TH;
-  const int gy0 = y0 - 3 - R;
-  u64* mrow = mask + ((size_t)f * (size_t)mask_words + d.mask_off);
-  // per frame: ORBX_MAX_LEVELS x ORBX_MAX_BANDS tile-row statistics, then one
-  // "dead from band" word per level
-  u64* fstat = row_stat ? row_stat + (size_t)f * ORBX_FAST_STAT_WORDS : nullptr;
-  u64* stat = fstat ? fstat + d.stat_index : nullptr;
-  u64* dead_from = fstat ? fstat + ORBX_MAX_LEVELS * ORBX_MAX_BANDS + d.l : nullptr;
-
-  // early exit: the tile rows above are complete and already hold >= cap survivors.
-  // An exiting tile stores nothing: its mask words are never looked at (the row-major
-  // walk of k_level_select ignores everything after the first cap survivors), and the
-  // proof for later tile rows needs only the rows above the first dead one.  The first
-  // tile that proves row b dead publishes 64-b in dead_from (monotone max), so that later
-  // tiles decide with one load.
-  if (stat && ty > 0) {
-    if (tid < 64) {
-      u64 st = 0;
-      if (tid < ty) st = __hip_atomic_load(&stat[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tid == 63) st = __hip_atomic_load(dead_from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int known = (int)__builtin_amdgcn_readlane((uint32_t)st, 63);  // 64 - (first dead row), 0: unknown
-      bool skip = known >= 64 - ty;
-      if (!skip) {
-        const bool complete = tid >= ty || (int)(st >> 32) == tiles_x;
-        const u64 inc = __ballot(!complete);                   // rows not yet complete
-        const int k = inc ? __ffsll((long long)inc) - 1 : 64;  // first incomplete row
-        const int surv = wave_sum(tid < k && tid < ty ? (int)(uint32_t)st : 0);
-        skip = surv >= L.cap;
-        if (skip && tid == 0)
-          __hip_atomic_fetch_max(dead_from, (u64)(64 - ty), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (tid == 0) s_skip = skip;
-    }
-    __syncthreads();
-    if (s_skip) return;
-  }
-
-  for (int tx = tx_first; tx < tx_first + n_strip; tx++) {
-  const int x0 = tx * TW;
-  // phase 1: tile + halo -> LDS with aligned 8-byte loads (x0-8 is 8-byte aligned).
-  // All loads of a thread are issued before the first is stored (one memory latency
-  // per tile instead of one per loop iteration).
-  {
-    constexpr int NLOADS = IMG_ROWS * (F2_IMG_DW / 2), NPT = (NLOADS + 255) / 256;
-    uint2 v[NPT];
-#pragma unroll
-    for (int k = 0; k < NPT; k++) {
-      const int i = tid + 256 * k;
-      const int row = i / (F2_IMG_DW / 2), c = i - row * (F2_IMG_DW / 2);
-      const int gy = gy0 + row, gx = x0 - 8 + 8 * c;
-      v[k] = make_uint2(0u, 0u);
-      // gx, pitch are multiples of 8: (unsigned)gx < pitch  <=>  0 <= gx && gx + 8 <= pitch
-      if (i < NLOADS && (unsigned)gy < (unsigned)L.h && (unsigned)gx < (unsigned)L.pitch)
-        v[k] = *reinterpret_cast<const uint2*>(img + (uint32_t)(gy * L.pitch + gx));
-    }
-#pragma unroll
-    for (int k = 0; k < NPT; k++)
-      if (tid + 256 * k < NLOADS) reinterpret_cast<uint2*>(s_img32)[tid + 256 * k] = v[k];
-  }
-  for (int i = tid; i < SC_ROWS * F2_SC_PITCH / 8; i += 256)
-    reinterpret_cast<uint4*>(s_score)[i] = make_uint4(0u, 0u, 0u, 0u);
-  if (tid < TH * 2) s_mask32[tid] = 0u;
-  if (tid == 0) s_qn = 0;
-  __syncthreads();
-
-  // phase 2: 4-point pre-test, one dword (4 pixels) per lane (src/orb_cpu.cpp:39-58).
-  // Each lane keeps the candidate bits of all its items in one register; the
-  // candidates are compacted into the LDS queue ONCE per tile (wave prefix sum
-  // of the popcounts + one LDS atomic per wave).
-  constexpr int NIT = (N_ITEMS + 255) / 256;
-  static_assert(NIT * 4 <= 32, "candidate bits must fit one register");
-  uint32_t cand_bits = 0;
-  {
-    const uint32_t t_hi = (uint32_t)thr * 0x00010001u;
-    // the reference's else-if makes "darker" strict when threshold == 0
-    const uint32_t t_lo = (uint32_t)(thr == 0 ? 1 : thr) * 0x00010001u;
-    // tiles whose whole score region lies inside [3,w-3) x [3,h-3) skip the per-item range tests
-    const bool interior = (x0 - 4 >= 3) && (x0 + F2_SC_PITCH - 4 <= L.w - 3) && (y0 - R >= 3) &&
-                          (y0 - R + SC_ROWS <= L.h - 3);
-    int sy = tid / F2_DCOLS, dc = tid - sy * F2_DCOLS;
-#pragma unroll
-    for (int j = 0; j < NIT; j++) {
-      if (tid + 256 * j < N_ITEMS) {
-        const int gy = y0 - R + sy, gx = x0 - 4 + 4 * dc;
-        if (interior || (gy >= 3 && gy < L.h - 3 && gx >= 0 && gx < L.w - 3)) {
-          const uint32_t* p = s_img32 + (sy + 3) * F2_IMG_DW + dc + 1;
-          const uint32_t C = p[0], Lw = p[-1], Rw = p[1], Nw = p[-3 * F2_IMG_DW], Sw = p[3 * F2_IMG_DW];
-          // even pixels (0,2) and odd pixels (1,3) of the dword as 16-bit lanes
-          const uint32_t ce = __builtin_amdgcn_perm(C, C, 0x0c020c00u), co = __builtin_amdgcn_perm(C, C, 0x0c030c01u);
-          const uint32_t ne = __builtin_amdgcn_perm(Nw, Nw, 0x0c020c00u), no = __builtin_amdgcn_perm(Nw, Nw, 0x0c030c01u);
-          const uint32_t se = __builtin_amdgcn_perm(Sw, Sw, 0x0c020c00u), so = __builtin_amdgcn_perm(Sw, Sw, 0x0c030c01u);
-          // east = x+3: px0 -> C.b3, px1 -> R.b0, px2 -> R.b1, px3 -> R.b2   (perm bytes: 0-3 = 2nd arg, 4-7 = 1st)
-          const uint32_t ee = __builtin_amdgcn_perm(Rw, C, 0x0c050c03u), eo = __builtin_amdgcn_perm(Rw, C, 0x0c060c04u);
-          // west = x-3: px0 -> L.b1, px1 -> L.b2, px2 -> L.b3, px3 -> C.b0
-          const uint32_t we = __builtin_amdgcn_perm(C, Lw, 0x0c030c01u), wo = __builtin_amdgcn_perm(C, Lw, 0x0c040c02u);
-          const uint32_t re = pretest_pk(ce, ne, ee, se, we, t_hi, t_lo);
-          const uint32_t ro = pretest_pk(co, no, eo, so, wo, t_hi, t_lo);
-          const uint32_t r2 = ((re >> 15) | (ro >> 14)) & 0x00030003u;  // bit0 px0, bit1 px1, bit16 px2, bit17 px3
-          uint32_t m4 = (r2 | (r2 >> 14)) & 0xfu;
-          if (!interior) {  // pixels outside [3, w-3) never become corners
-            const int lo = max(0, 3 - gx), hi = min(4, L.w - 3 - gx);
-            m4 &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-          }
-          cand_bits |= m4 << (4 * j);
-        }
-      }
-      // item i + 256: 256 = 14 * 18 + 4
-      sy += 256 / F2_DCOLS;
-      dc += 256 % F2_DCOLS;
-      if (dc >= F2_DCOLS) {
-        dc -= F2_DCOLS;
-        sy += 1;
-      }
-    }
-  }
-  const uint32_t my_cands = cand_bits;  // kept for the queue-less overflow path
-  {
-    const int lane = tid & 63;
-    const int cnt = __popc(cand_bits);
-    const int incl = wave_scan_incl(cnt);
-    int wbase = 0;
-    if (lane == 63) wbase = atomicAdd(&s_qn, incl);
-    wbase = __builtin_amdgcn_readlane(wbase, 63);
-    int pos = wbase + incl - cnt;
-    while (cand_bits) {
-      const int bpos = __ffs(cand_bits) - 1;
-      cand_bits &= cand_bits - 1;
-      const int i = tid + 256 * (bpos >> 2);
-      const int isy = i / F2_DCOLS, idc = i - isy * F2_DCOLS;
-      if (pos < F2_QCAP) s_queue[pos] = (uint16_t)(isy * F2_SC_PITCH + 4 * idc + (bpos & 3));
-      pos++;
-    }
-  }
-  __syncthreads();
-
-  // phase 3: full segment test + score on the compacted candidates (src/orb_cpu.cpp:61-101)
-  const uint8_t* s_img = reinterpret_cast<const uint8_t*>(s_img32);
-  const int ntot = s_qn;
-  const bool overflow = ntot > F2_QCAP;  // block-uniform
-  const int nq = overflow ? 0 : ntot;
-  auto score_candidate = [&](int pos) {
-    const int sy = pos / F2_SC_PITCH, sx = pos - sy * F2_SC_PITCH;
-    const uint8_t* p = s_img + (sy + 3) * F2_IMG_PITCH + (sx + 4);
-    const int Ip = p[0], hi = Ip + thr, lo = Ip - thr;
-    const int ring[16] = {p[-3 * F2_IMG_PITCH],     p[-3 * F2_IMG_PITCH + 1], p[-2 * F2_IMG_PITCH + 2],
-                          p[-1 * F2_IMG_PITCH + 3], p[3],                     p[F2_IMG_PITCH + 3],
-                          p[2 * F2_IMG_PITCH + 2],  p[3 * F2_IMG_PITCH + 1],  p[3 * F2_IMG_PITCH],
-                          p[3 * F2_IMG_PITCH - 1],  p[2 * F2_IMG_PITCH - 2],  p[F2_IMG_PITCH - 3],
-                          p[-3],                    p[-F2_IMG_PITCH - 3],     p[-2 * F2_IMG_PITCH - 2],
-                          p[-3 * F2_IMG_PITCH - 1]};
-    // the sign bits of (v - hi) and (lo - v) are shifted into the masks with one v_alignbit each
-    // (2 ops per ring pixel and mask instead of compare + select + shift-or); the masks come out
-    // inverted and in reverse ring order, which a circular run test does not mind
-    uint32_t nb = 0, nd = 0;
-    int score = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const int v = ring[k];
-      nb = __builtin_amdgcn_alignbit(nb, (uint32_t)(v - hi), 31);  // bit = v < hi
-      nd = __builtin_amdgcn_alignbit(nd, (uint32_t)(lo - v), 31);  // bit = v > lo
-      score += abs(Ip - v);
-    }
-    const uint32_t bmk = ~nb & 0xffffu, dmk = ~nd & 0xffffu;
-    if (has_run16(bmk, fp.n) || has_run16(dmk, fp.n)) s_score[pos] = (uint16_t)score;
-  };
-  // position of candidate bit `bpos` of this thread (same mapping as the compaction above)
-  auto bit_pos = [&](int bpos) {
-    const int i = tid + 256 * (bpos >> 2);
-    const int isy = i / F2_DCOLS, idc = i - isy * F2_DCOLS;
-    return isy * F2_SC_PITCH + 4 * idc + (bpos & 3);
-  };
-  for (int q = tid; q < nq; q += 256) score_candidate(s_queue[q]);
-  if (overflow)
-    for (uint32_t b = my_cands; b; b &= b - 1) score_candidate(bit_pos(__ffs(b) - 1));
-  __syncthreads();
-
-  // phase 4: NMS, corners only (ties survive, src/orb_cpu.cpp:110-133); survivors
-  // of the tile interior set their bit in the LDS mask
-  auto nms_candidate = [&](int pos) {
-    const int s = s_score[pos];
-    if (s > 0) {
-      const int sy = pos / F2_SC_PITCH, sx = pos - sy * F2_SC_PITCH;
-      const int iy = sy - R, ix = sx - 4;
-      if (iy >= 0 && iy < TH && ix >= 0 && ix < TW) {
-        bool keep = true;
-#pragma unroll
-        for (int dy = -R; dy <= R; dy++)
-#pragma unroll
-          for (int dx = -R; dx <= R; dx++) keep = keep && !(s_score[pos + dy * F2_SC_PITCH + dx] > s);
-        if (keep) atomicOr(&s_mask32[iy * 2 + (ix >> 5)], 1u << (ix & 31));
-      }
-    }
-  };
-  {
-    for (int q = tid; q < nq; q += 256) nms_candidate(s_queue[q]);
-    if (overflow)
-      for (uint32_t b = my_cands; b; b &= b - 1) nms_candidate(bit_pos(__ffs(b) - 1));
-  }
-  __syncthreads();
-
-  // phase 5: one 8-byte store per tile row (TH == 64: exactly wave 0), and the
-  // tile's survivor count joins the tile-row statistics
-  if (tid < TH) {
-    const int gy = y0 + tid;
-    const u64 word = reinterpret_cast<const u64*>(s_mask32)[tid];
-    if (gy < L.h) mrow[(size_t)gy * L.mask_wpr + tx] = word;
-    if (stat) {
-      const int surv = wave_sum(gy < L.h ? __popcll(word) : 0);
-      if (tid == 0)
-        __hip_atomic_fetch_add(&stat[ty], (1ull << 32) | (u64)(uint32_t)surv, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  if (WRITE_SCORES) {
-    for (int i = tid; i < TH * TW; i += 256) {
-      const int iy = i / TW, ix = i - iy * TW;
-      const int gy = y0 + iy, gx = x0 + ix;
-      if (gy < L.h && gx < L.w) scores_dbg[(size_t)gy * L.w + gx] = s_score[(iy + R) * F2_SC_PITCH + ix + 4];
-    }
-  }
-  if (tx + 1 < tx_first + n_strip) __syncthreads();  // the LDS tiles are reused by the next tile of the strip
-  }
-}
+// (3. FAST-n segment test + score + NMS: orbx_fast.hip)
 
 // ---------------------------------------------------------------------------
 // 4. (stage operators Fast()/NMS() only; the whole path uses the fused kernel below)
@@ -2155,44 +1807,6 @@ hipError_t orbx_launch_blur2(hipStream_t s, const OrbxTileDesc* d_tiles, int n_t
     hipLaunchKernelGGL(k_blur2<32>, grid, dim3(256), 0, s, d_tiles, frame_bytes, d_src, d_dst, first_level);
   else
     hipLaunchKernelGGL(k_blur2<16>, grid, dim3(256), 0, s, d_tiles, frame_bytes, d_src, d_dst, first_level);
-  return ORBX_LAUNCH_CHECK();
-}
-
-template <int R>
-static void launch_fast2(dim3 grid, hipStream_t s, const OrbxTileDesc* d_tiles, const uint8_t* d_pyr, int frame_bytes,
-                         int mask_words, OrbxFastParams fp, unsigned long long* d_mask, uint16_t* d_scores_dbg,
-                         unsigned long long* d_row_stat) {
-  if (d_scores_dbg)
-    hipLaunchKernelGGL((k_fast_nms2<R, true>), grid, dim3(256), 0, s, d_tiles, d_pyr, frame_bytes, mask_words, fp,
-                       d_mask, d_scores_dbg, d_row_stat);
-  else
-    hipLaunchKernelGGL((k_fast_nms2<R, false>), grid, dim3(256), 0, s, d_tiles, d_pyr, frame_bytes, mask_words, fp,
-                       d_mask, d_scores_dbg, d_row_stat);
-}
-
-// d_tiles: the n_tiles tiles of ONE frame in band-major order; grid = (frames, tiles).
-// d_row_stat: n_frames * ORBX_FAST_STAT_WORDS zeroed u64 (or NULL: no early exit)
-hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int n_frames,
-                                const uint8_t* d_pyr, int frame_bytes, int mask_words, OrbxFastParams fp,
-                                unsigned long long* d_mask, uint16_t* d_scores_dbg,
-                                unsigned long long* d_row_stat) {
-  if (n_tiles <= 0 || n_frames <= 0) return hipSuccess;
-  if (n_tiles > 65535) return hipErrorInvalidValue;
-  dim3 grid(n_frames, n_tiles);
-  switch (fp.nms_radius) {
-    case 0:
-      launch_fast2<0>(grid, s, d_tiles, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores_dbg, d_row_stat);
-      break;
-    case 1:
-      launch_fast2<1>(grid, s, d_tiles, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores_dbg, d_row_stat);
-      break;
-    case 2:
-      launch_fast2<2>(grid, s, d_tiles, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores_dbg, d_row_stat);
-      break;
-    default:
-      launch_fast2<3>(grid, s, d_tiles, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores_dbg, d_row_stat);
-      break;
-  }
   return ORBX_LAUNCH_CHECK();
 }
 
