@@ -239,6 +239,7 @@ int make_bandmap(const OrbxPlan& plan, int nms_radius, OrbxBandMap* bm, std::str
   for (int l = 0; l < plan.nlevels; l++) {
     bm->tiles_x[l] = (plan.L[l].w + tw - 1) / tw;
     bm->tiles_y[l] = (plan.L[l].h + th - 1) / th;
+    bm->tile_h[l] = (plan.L[l].h + bm->tiles_y[l] - 1) / bm->tiles_y[l];  // balanced tile rows
     bm->xprefix[l + 1] = bm->xprefix[l] + bm->tiles_x[l];
     if (l > 0 && bm->tiles_y[l] > bm->tiles_y[l - 1]) {
       *why = "pyramid levels must not grow with the level index";
@@ -276,7 +277,7 @@ void build_fast_tiles(const OrbxPlan& plan, const OrbxBandMap& bm, int first_ban
         d.l = l;
         d.tx = tx;
         d.ty = b;
-        d.f = std::min(strip, bm.tiles_x[l] - tx);  // tiles in this workgroup's strip
+        d.f = bm.tile_h[l];
         d.w = L.w;
         d.h = L.h;
         d.pitch = L.pitch;

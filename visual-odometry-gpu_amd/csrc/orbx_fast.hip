@@ -5,6 +5,9 @@
 //
 // The kernel is bound by VALU issue, not by memory (profiles/r01/pmc_sq.md), so the design is about
 // wave-instructions per pixel:
+//   Tiles are 128 pixels wide and up to 56 - 2R rows tall; the host balances the tile rows of a
+//   level (a 218-row level gets 5 tile rows of 44, not 4 of 54 and one of 2), and the walking
+//   threads then take 7 instead of 8 rows each.
 //   phase 1  tile + halo -> LDS, row-coalesced 8-byte loads (zero outside the image).
 //   phase 2  4-point pre-test on EVERY pixel.  A thread owns one dword column (4 pixels) of the
 //            score region and walks K = 8 rows of it: each image row is unpacked ONCE into packed
@@ -12,8 +15,9 @@
 //            different steps; the pre-test itself is a 8-op v_pk_min/max_u16 network per pixel pair
 //            (2nd smallest / 2nd largest of N,E,S,W) + 4 packed ops for both polarities.  The
 //            candidate flags of the 8 rows x 4 pixels end up in one register per thread.
-//   phase 3  the candidates (~6 % of the pixels) are compacted once per tile into an LDS queue and
-//            evaluated 64 per wave: one ring pixel per ds_read_u8, ONE v_cmp per ring pixel and
+//   phase 3  every wave compacts its candidates (~3-6 % of the pixels) into its own LDS queue (no
+//            atomics, no barrier) and evaluates them 64 at a time: one ring pixel per ds_read_u8,
+//            ONE v_cmp per ring pixel and
 //            polarity whose result is a 64-bit scalar lane mask -- the 9-contiguous-arc test then
 //            runs on the SCALAR unit (AND-doubling over the 16 masks), off the VALU; score =
 //            16 v_sad_u32.
@@ -41,7 +45,7 @@ struct F3 {
   static constexpr int IMG_DW = IMG_PITCH / 4;
   static constexpr int IMG_ROWS = SC_ROWS + 6;   // y0-R-3 .. y0+TH+R+3
   static constexpr int SC_PITCH = NC * 4;        // u16 elements
-  static constexpr int QCAP = 1024;              // candidate queue entries (more candidates: several passes)
+  static constexpr int QCAP = 736;               // candidate queue entries (more candidates: several passes)
   static constexpr int MASK_DW = TW / 32;        // mask dwords per tile row
 };
 static_assert(F3<1>::NC == 34 && F3<1>::NSEG == 7 && F3<1>::K == 8, "walk mapping (tid / 34 by multiply-shift) assumes 34 x 7");
@@ -64,16 +68,19 @@ __device__ __forceinline__ uint32_t f3_pretest(uint32_t ip, uint32_t a, uint32_t
   return ZT ? r : pk_sub(r, T);
 }
 
-// the walk of one thread: candidate flags of K rows x 4 pixels, byte b = pixel b of the dword,
-// bit k = row k of the walk (before border masking).  p points at the dword LEFT of the thread's
-// column in the first image row of the walk (row seg*K of the LDS image = score row seg*K - 3).
+// the walk of one thread: candidate flags of `keff` (<= K) rows x 4 pixels, byte b = pixel b of the
+// dword, bit k = row k of the walk (before border masking).  p points at the dword LEFT of the
+// thread's column in the first image row of the walk (LDS image row seg*keff = score row
+// seg*keff - 3).  keff is uniform over the workgroup: the early break is a scalar branch.
 template <int R, bool ZT>
-__device__ __forceinline__ uint32_t f3_walk(const uint32_t* p, uint32_t T) {
+__device__ __forceinline__ uint32_t f3_walk(const uint32_t* p, uint32_t T, int keff) {
   typedef F3<R> G;
   uint32_t E[G::K + 6], O[G::K + 6];
   uint32_t acc = 0;  // bit SET = not a candidate
 #pragma unroll
   for (int i = 0; i < G::K + 6; i++) {
+    // (no `break`: it would keep the loop rolled, with E/O indexed through M0)
+    if (i >= G::K + 5 && keff < G::K) continue;  // keff is K or K-1: only the last step is optional
     const uint32_t c = p[i * G::IMG_DW + 1];
     // even pixels (0,2) and odd pixels (1,3) of the dword as 16-bit lanes
     E[i] = __builtin_amdgcn_perm(c, c, 0x0c020c00u);
@@ -88,12 +95,12 @@ __device__ __forceinline__ uint32_t f3_walk(const uint32_t* p, uint32_t T) {
       const uint32_t we = __builtin_amdgcn_perm(Cw, Lw, 0x0c030c01u), wo = __builtin_amdgcn_perm(Cw, Lw, 0x0c040c02u);
       const uint32_t ze = f3_pretest<ZT>(E[j], E[j - 3], ee, E[j + 3], we, T);
       const uint32_t zo = f3_pretest<ZT>(O[j], O[j - 3], eo, O[j + 3], wo, T);
-      // the four sign bytes (px0..px3) side by side; row k ends up in bit k of every byte
+      // the four sign bytes (px0..px3) side by side; after K steps row k sits in bit k of every byte
       const uint32_t F = __builtin_amdgcn_perm(zo, ze, 0x07030501u);
       acc = (F & 0x80808080u) | (acc >> 1);
     }
   }
-  return ~acc;
+  return ~acc >> (G::K - keff);  // (fewer than K steps: the rows have not travelled all the way down)
 }
 
 // exists i: ring pixels i .. i+NARC-1 all pass, on the circular 16-ring (src/orb_cpu.cpp:71-89).
@@ -129,6 +136,31 @@ __device__ __forceinline__ u64 f3_has_arc(const u64 (&m)[16]) {
   return any;
 }
 
+// n = 9 (the ORB default): 16 = 2 * (9 - 1), so every 9-window is a suffix of one half of the ring
+// followed by a prefix of the other half (van Herk / Gil-Werman): 44 ANDs + 15 ORs instead of 64 + 15.
+template <>
+__device__ __forceinline__ u64 f3_has_arc<9>(const u64 (&m)[16]) {
+  u64 sA[8], pA[8], sB[8], pB[8];
+  sA[7] = m[7];
+  pA[0] = m[0];
+  sB[7] = m[15];
+  pB[0] = m[8];
+#pragma unroll
+  for (int j = 6; j >= 0; j--) {
+    sA[j] = m[j] & sA[j + 1];
+    sB[j] = m[8 + j] & sB[j + 1];
+  }
+#pragma unroll
+  for (int j = 1; j < 8; j++) {
+    pA[j] = pA[j - 1] & m[j];
+    pB[j] = pB[j - 1] & m[8 + j];
+  }
+  u64 any = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) any |= (sA[i] & pB[i]) | (sB[i] & pA[i]);  // windows starting at i and at 8 + i
+  return any;
+}
+
 // run of >= n set bits in the circular 16-bit mask (any n; per-lane arithmetic)
 __device__ __forceinline__ bool f3_has_run16(uint32_t m, int n) {
   const uint32_t x = m | (m << 16);
@@ -151,11 +183,11 @@ struct F3Ring {
 };
 
 // queue entry (walking thread, flag index) -> score-region row / column
-__device__ __forceinline__ void f3_decode(uint32_t e, int K, int& sr, int& sc) {
+__device__ __forceinline__ void f3_decode(uint32_t e, int keff, int& sr, int& sc) {
   const uint32_t t = e >> 5, bi = e & 31u;
   const uint32_t seg = (t * 241u) >> 13;  // t / 34 for t < 256
   const uint32_t col = t - seg * 34u;
-  sr = (int)(seg * (uint32_t)K + (bi & 7u));
+  sr = (int)(seg * (uint32_t)keff + (bi & 7u));
   sc = (int)(col * 4u + (bi >> 3));
 }
 
@@ -163,7 +195,7 @@ __device__ __forceinline__ void f3_decode(uint32_t e, int K, int& sr, int& sc) {
 // NARC > 0: arc length known at compile time, scalar arc test; NARC == 0: any n, per-lane masks.
 template <int R, int NARC>
 __device__ __forceinline__ void f3_eval(const uint8_t* s_img, uint16_t* s_score, uint16_t* s_queue, int nq, int thr,
-                                        int n, int tid) {
+                                        int n, int keff, int tid) {
   typedef F3<R> G;
   typedef F3Ring<G::IMG_PITCH> RG;
   for (int q0 = (tid & ~63); q0 < nq; q0 += 256) {  // wave-uniform
@@ -171,7 +203,7 @@ __device__ __forceinline__ void f3_eval(const uint8_t* s_img, uint16_t* s_score,
     const bool active = q < nq;
     const uint32_t e = active ? s_queue[q] : 0u;
     int sr, sc;
-    f3_decode(e, G::K, sr, sc);
+    f3_decode(e, keff, sr, sc);
     const int pos = sr * G::SC_PITCH + sc;
     if (active) s_queue[q] = (uint16_t)pos;  // the NMS pass reads positions
     const uint8_t* p0 = s_img + sr * G::IMG_PITCH + sc + 1;  // pixel (x-3, y-3)
@@ -209,7 +241,7 @@ __device__ __forceinline__ void f3_eval(const uint8_t* s_img, uint16_t* s_score,
 // the tile interior set their bit in the LDS mask
 template <int R>
 __device__ __forceinline__ void f3_nms(const uint16_t* s_score, const uint16_t* s_queue, int nq, uint32_t* s_mask32,
-                                       int tid) {
+                                       int th, int tid) {
   typedef F3<R> G;
   for (int q0 = (tid & ~63); q0 < nq; q0 += 256) {
     const int q = q0 + (tid & 63);
@@ -218,7 +250,7 @@ __device__ __forceinline__ void f3_nms(const uint16_t* s_score, const uint16_t* 
       const int s = s_score[pos];
       const int sr = pos / G::SC_PITCH, sc = pos - sr * G::SC_PITCH;
       const int iy = sr - R, ix = sc - 4;
-      bool keep = s > 0 && iy >= 0 && iy < G::TH && ix >= 0 && ix < G::TW;
+      bool keep = s > 0 && iy >= 0 && iy < th && ix >= 0 && ix < G::TW;
 #pragma unroll
       for (int dy = -R; dy <= R; dy++)
 #pragma unroll
@@ -253,10 +285,14 @@ __global__ __launch_bounds__(256) void k_fast3(const OrbxTileDesc* __restrict__ 
   const OrbxTileDesc d = tiles[blockIdx.y];
   const int w = d.w, h = d.h, pitch = d.pitch, cap = d.u0, mask_wpr = d.u1, tiles_x = d.u2;
   const int tx = d.tx, ty = d.ty;
+  // tile height of this level (<= G::TH; the host balances the tile rows of a level) and the rows
+  // each walking thread then owns (K, or K-1 for the shorter tiles)
+  const int th = d.f;
+  const int keff = (th + 2 * R + G::NSEG - 1) / G::NSEG >= G::K ? G::K : G::K - 1;
   const uint8_t* img = pyr + ((size_t)f * (size_t)frame_bytes + d.img_off);
   const int tid = threadIdx.x;
   const int thr = fp.threshold;
-  const int x0 = tx * G::TW, y0 = ty * G::TH;
+  const int x0 = tx * G::TW, y0 = ty * th;
   u64* mrow = mask + ((size_t)f * (size_t)mask_words + d.mask_off);
   // per frame: ORBX_MAX_LEVELS x ORBX_MAX_BANDS tile-row statistics, then one "dead from tile row"
   // word per level
@@ -298,6 +334,7 @@ __global__ __launch_bounds__(256) void k_fast3(const OrbxTileDesc* __restrict__ 
     constexpr int CPR = G::IMG_PITCH / 8;  // 18 loads per row
     constexpr int RPP = 256 / CPR;         // 14 rows per pass
     constexpr int NP = (G::IMG_ROWS + RPP - 1) / RPP;
+    const int img_rows = th + 2 * R + 6;   // <= G::IMG_ROWS
     const int r0 = (tid * 3641) >> 16;     // tid / 18
     const int c = tid - r0 * CPR;
     const int gx = x0 - 8 + 8 * c;
@@ -308,7 +345,7 @@ __global__ __launch_bounds__(256) void k_fast3(const OrbxTileDesc* __restrict__ 
     for (int k = 0; k < NP; k++) {
       const int gy = gy0 + RPP * k;
       v[k] = make_uint2(0u, 0u);
-      if (xok && (unsigned)gy < (unsigned)h && r0 + RPP * k < G::IMG_ROWS)
+      if (xok && (unsigned)gy < (unsigned)h && r0 + RPP * k < img_rows)
         v[k] = *reinterpret_cast<const uint2*>(img + (uint32_t)(gy * pitch + gx));
     }
     // zero the score tile (and its guard rows) and the survivor mask while the loads are in flight
@@ -323,7 +360,7 @@ __global__ __launch_bounds__(256) void k_fast3(const OrbxTileDesc* __restrict__ 
     }
 #pragma unroll
     for (int k = 0; k < NP; k++)
-      if (r0 < RPP && r0 + RPP * k < G::IMG_ROWS)
+      if (r0 < RPP && r0 + RPP * k < img_rows)
         reinterpret_cast<uint2*>(s_img32)[(r0 + RPP * k) * CPR + c] = v[k];
   }
   __syncthreads();
@@ -333,19 +370,18 @@ __global__ __launch_bounds__(256) void k_fast3(const OrbxTileDesc* __restrict__ 
   {
     const int seg = (tid * 241) >> 13;  // tid / 34
     const int col = tid - seg * G::NC;
-    const int gy_first = y0 - R + seg * G::K;  // image row of walk row 0
-    // rows that can hold a corner: 3 <= gy < h-3 (src/orb_cpu.cpp:35); a wave whose rows all lie
-    // outside skips the walk
-    if (seg < G::NSEG && gy_first < h - 3 && gy_first + G::K > 3) {
-      const uint32_t* p = s_img32 + (seg * G::K) * G::IMG_DW + col;
+    const int gy_first = y0 - R + seg * keff;  // image row of walk row 0
+    // rows that can hold a corner: 3 <= gy < h-3 (src/orb_cpu.cpp:35) and that this tile needs
+    const int lo_y = max(3 - gy_first, 0), hi_y = min(min(h - 3, y0 + th + R) - gy_first, keff);
+    if (seg < G::NSEG && hi_y > lo_y) {  // (a wave whose rows all lie outside skips the walk)
+      const uint32_t* p = s_img32 + (seg * keff) * G::IMG_DW + col;
       const uint32_t T = (uint32_t)thr * 0x00010001u;
-      cand = thr == 0 ? f3_walk<R, true>(p, T) : f3_walk<R, false>(p, T);
+      cand = thr == 0 ? f3_walk<R, true>(p, T, keff) : f3_walk<R, false>(p, T, keff);
       // pixels that can hold a corner and that this tile needs: 3 <= gx < w-3, x0-R <= gx < x0+TW+R
       const int gx = x0 - 4 + 4 * col;
       const int lo_x = max(max(3, x0 - R) - gx, 0), hi_x = min(min(w - 3, x0 + G::TW + R) - gx, 4);
       const uint32_t cm = hi_x > lo_x ? ((0xffffffffu >> (32 - 8 * hi_x)) & ~((1u << (8 * lo_x)) - 1u)) : 0u;
-      const int lo_y = max(3 - gy_first, 0), hi_y = min(h - 3 - gy_first, G::K);
-      const uint32_t rm = hi_y > lo_y ? (((1u << hi_y) - 1u) & ~((1u << lo_y) - 1u)) * 0x01010101u : 0u;
+      const uint32_t rm = (((1u << hi_y) - 1u) & ~((1u << lo_y) - 1u)) * 0x01010101u;
       cand &= cm & rm;
     }
   }
@@ -379,18 +415,18 @@ __global__ __launch_bounds__(256) void k_fast3(const OrbxTileDesc* __restrict__ 
   const int n = fp.n;
   auto eval = [&](int nq) {
     if (n == 9)
-      f3_eval<R, 9>(s_img, score0, s_queue, nq, thr, n, tid);
+      f3_eval<R, 9>(s_img, score0, s_queue, nq, thr, n, keff, tid);
     else if (n == 12)
-      f3_eval<R, 12>(s_img, score0, s_queue, nq, thr, n, tid);
+      f3_eval<R, 12>(s_img, score0, s_queue, nq, thr, n, keff, tid);
     else
-      f3_eval<R, 0>(s_img, score0, s_queue, nq, thr, n, tid);
+      f3_eval<R, 0>(s_img, score0, s_queue, nq, thr, n, keff, tid);
   };
   if (ntot <= G::QCAP) {  // block-uniform
     // ---- phase 3: full segment test + score of the candidates
     eval(ntot);
     __syncthreads();
     // ---- phase 4: NMS
-    f3_nms<R>(score0, s_queue, ntot, s_mask32, tid);
+    f3_nms<R>(score0, s_queue, ntot, s_mask32, th, tid);
   } else {
     // more candidates than the queue holds (noise, tiny thresholds): windows of QCAP candidates in
     // a fixed order (wave bases from the per-wave totals, not from the atomic)
@@ -420,11 +456,11 @@ __global__ __launch_bounds__(256) void k_fast3(const OrbxTileDesc* __restrict__ 
       const int nq = min(G::QCAP, ntot - base);
       for (int q = tid; q < nq; q += 256) {
         int sr, sc;
-        f3_decode(s_queue[q], G::K, sr, sc);
+        f3_decode(s_queue[q], keff, sr, sc);
         s_queue[q] = (uint16_t)(sr * G::SC_PITCH + sc);
       }
       __syncthreads();
-      f3_nms<R>(score0, s_queue, nq, s_mask32, tid);
+      f3_nms<R>(score0, s_queue, nq, s_mask32, th, tid);
     }
   }
   __syncthreads();
@@ -434,7 +470,7 @@ __global__ __launch_bounds__(256) void k_fast3(const OrbxTileDesc* __restrict__ 
   {
     constexpr int WPR = G::TW / 64;  // mask words per tile row
     int surv = 0;
-    if (tid < G::TH * WPR) {
+    if (tid < th * WPR) {
       const int iy = tid / WPR, wj = tid - iy * WPR;
       const int gy = y0 + iy, gw = tx * WPR + wj;
       const u64 word = reinterpret_cast<const u64*>(s_mask32)[tid];
@@ -456,7 +492,7 @@ __global__ __launch_bounds__(256) void k_fast3(const OrbxTileDesc* __restrict__ 
     }
   }
   if (scores_out) {  // stage operator Fast()/orbx_fast_score: the dense score map
-    for (int i = tid; i < G::TH * G::TW; i += 256) {
+    for (int i = tid; i < th * G::TW; i += 256) {
       const int iy = i / G::TW, ix = i - iy * G::TW;
       const int gy = y0 + iy, gx = x0 + ix;
       if (gy < h && gx < w) scores_out[(size_t)gy * w + gx] = score0[(iy + R) * G::SC_PITCH + ix + 4];

@@ -56,6 +56,7 @@ struct OrbxBandMap {
   int32_t band_begin[ORBX_MAX_BANDS + 1];  // tiles PER FRAME before band b (+ total)
   int32_t tiles_x[ORBX_MAX_LEVELS];
   int32_t tiles_y[ORBX_MAX_LEVELS];
+  int32_t tile_h[ORBX_MAX_LEVELS];       // rows per FAST tile of the level (balanced: ceil(h / tiles_y))
   int32_t xprefix[ORBX_MAX_LEVELS + 1];  // prefix sums of tiles_x
 };
 
@@ -64,8 +65,8 @@ struct OrbxBandMap {
 // scalar loads that decoding blockIdx through the plan / tile maps costs at the
 // start of every wave (~20 s_load round trips for the FAST kernel).
 //   FAST table   : one entry per (tile row, level, tx) of ONE frame in band-major order
-//                  (grid = frames x tiles, frame index dispatched fastest); `f` = tiles the
-//                  workgroup owns along its tile row (1 in production).
+//                  (grid = frames x tiles, frame index dispatched fastest); `f` = rows per tile
+//                  of this level.
 //   blur/pyramid : one entry per (level, tx, ty) of ONE frame (blockIdx.y = frame); u0/u1/u2
 //                  carry xtab_off / ytab_off / win8 and `f` the rows per wave (pyramid only).
 //   img_off / mask_off are offsets inside one frame's pyramid / mask block.
