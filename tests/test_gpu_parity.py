@@ -315,12 +315,15 @@ def test_fast_early_exit_is_invisible(pkg, kitti0, kitti1):
     assert np.array_equal(r["desc"][0] & valid, desc & valid)
 
 
-@pytest.mark.parametrize("w", [8, 9, 10, 11, 63, 64, 65, 243, 244, 245, 246, 247, 248, 249, 250, 251, 252, 253, 255, 256,
-                               257, 492, 495, 496, 497, 500, 744, 745])
+@pytest.mark.parametrize("w", [8, 9, 10, 11, 63, 64, 65, 243, 244, 245, 246, 247, 248, 249, 250, 251, 252, 253, 254, 255, 256,
+                               257, 258, 259, 260, 261, 492, 495, 496, 497, 500, 508, 509, 511, 512, 513, 514, 516, 744, 745,
+                               767, 768, 769, 770, 772])
 def test_blur_width_sweep(ctx, w):
-    """k_blur2 strip / lane boundaries: the dword holding the last pixel falls on every lane position
-    (incl. the halo lanes 0 and 63 of a 248-pixel strip) and every byte position."""
-    for h in (8, 17, 64, 65):
+    """Streaming-blur strip / lane boundaries: the dword holding the last pixel falls on every lane
+    position (incl. lanes 0 and 63 of a 256-pixel strip, whose outer neighbours are fetched from memory
+    rather than from a lane) and every byte position; heights around the 64-row band and the
+    5-row group boundaries."""
+    for h in (8, 17, 64, 65, 66, 69, 70, 71, 129):
         img = synth(w * 131 + h, h, w, "noise")
         assert np.array_equal(ctx.blur5_sep(img), O.blur5_sep(img)), (w, h)
 

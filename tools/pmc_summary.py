@@ -10,7 +10,7 @@ for pat in sys.argv[1:]:
         rows = list(csv.DictReader(open(f)))
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in rows:
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:26]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:26]
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         print("==", f)
         for k, v in agg.items():

@@ -323,6 +323,30 @@ void build_frame_tiles(const OrbxPlan& plan, int tw, int th, bool pyramid_fields
   }
 }
 
+// strips of the streaming blur for ONE frame: per level ceil(pitch / 256) strips x balanced row bands of
+// at most ORBX_BLUR3_RH rows (one wave each; the 4 warm-up rows of the vertical pass are per band)
+void build_blur_tiles(const OrbxPlan& plan, std::vector<OrbxTileDesc>* out) {
+  out->clear();
+  for (int l = 0; l < plan.nlevels; l++) {
+    const OrbxLevel& L = plan.L[l];
+    const int ntx = (L.pitch + ORBX_BLUR3_TW - 1) / ORBX_BLUR3_TW;  // the padding bytes are (re)written as zeros
+    const int nb = (L.h + ORBX_BLUR3_RH - 1) / ORBX_BLUR3_RH, rows = (L.h + nb - 1) / nb;
+    for (int b = 0; b < nb; b++)
+      for (int tx = 0; tx < ntx; tx++) {
+        OrbxTileDesc d{};
+        d.l = l;
+        d.tx = tx;
+        d.ty = b * rows;
+        d.f = std::min(rows, L.h - b * rows);
+        d.w = L.w;
+        d.h = L.h;
+        d.pitch = L.pitch;
+        d.img_off = (uint64_t)L.img_off;
+        if (d.f > 0) out->push_back(d);
+      }
+  }
+}
+
 int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string* why) {
   std::memset(plan, 0, sizeof(*plan));
   plan->nlevels = p.nlevels;
@@ -494,7 +518,7 @@ int set_plan(orbx_ctx* c, int w, int h) {
   if ((st = make_bandmap(plan, c->p.nms_window / 2, &c->bm_fast, &why)) != ORBX_OK) return fail(c, st, why);
   {
     std::vector<OrbxTileDesc> t;
-    build_frame_tiles(plan, ORBX_BLUR2_TW, 4 * orbx_blur2_rows_per_wave(), false, &t);
+    build_blur_tiles(plan, &t);
     if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "blur tile table exceeds pool");
     HIPCHK(c, hipMemcpy(c->d_tiles_blur2, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
     c->blur2_tiles_count = (int)t.size();
@@ -560,7 +584,7 @@ hipError_t launch_blur_auto(hipStream_t s, const OrbxPlan& P, const OrbxTileMap&
     return e ? atoi(e) : 2;
   }();
   if (kind == ORBX_BLUR_SEP16 && impl != 1)
-    return orbx_launch_blur2(s, tiles2, ntiles2, P.frame_bytes, n, src, dst, first_level);
+    return orbx_launch_blur3(s, tiles2, ntiles2, P.frame_bytes, n, src, dst, first_level);
   return orbx_launch_blur(s, P, tm1, n, src, dst, first_level, kind);
 }
 const uint8_t* final_pyr(const orbx_ctx* c) { return blur_enabled(c) ? c->d_pyr_blur : c->d_pyr; }
@@ -871,7 +895,7 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
     c->tiles_fast_capacity = (size_t)bmm.band_begin[bmm.nbands];
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_fast, std::max<size_t>(c->tiles_fast_capacity, 1) * sizeof(OrbxTileDesc)));
     std::vector<OrbxTileDesc> t1, t2;
-    build_frame_tiles(M, ORBX_BLUR2_TW, 4 * 16, false, &t1);  // the smaller strip height gives the larger table
+    build_blur_tiles(M, &t1);
     build_frame_tiles(M, ORBX_PYR2_TW, ORBX_PYR2_TH, true, &t2);
     c->tiles_frame_capacity = std::max(t1.size(), t2.size()) + 64;
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_blur2, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
@@ -1321,7 +1345,7 @@ static int blur_stage(orbx_ctx* c, const uint8_t* image, int width, int height, 
   OrbxTileMap tm;
   make_tilemap(P, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &tm);
   std::vector<OrbxTileDesc> t;
-  build_frame_tiles(P, ORBX_BLUR2_TW, 4 * orbx_blur2_rows_per_wave(), false, &t);
+  build_blur_tiles(P, &t);
   if ((st = ensure(c, c->s_tiles, t.size() * sizeof(OrbxTileDesc))) != ORBX_OK) return st;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->s_tiles.p, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));

@@ -67,8 +67,10 @@ struct OrbxBandMap {
 //   FAST table   : one entry per (tile row, level, tx) of ONE frame in band-major order
 //                  (grid = frames x tiles, frame index dispatched fastest); `f` = rows per tile
 //                  of this level.
-//   blur/pyramid : one entry per (level, tx, ty) of ONE frame (blockIdx.y = frame); u0/u1/u2
-//                  carry xtab_off / ytab_off / win8 and `f` the rows per wave (pyramid only).
+//   pyramid      : one entry per (level, tx, ty) of ONE frame (blockIdx.y = frame); u0/u1/u2
+//                  carry xtab_off / ytab_off / win8 and `f` the rows per wave.
+//   blur         : one entry per (level, 256-px strip, row band): tx = strip, ty = first row,
+//                  f = rows of the band.
 //   img_off / mask_off are offsets inside one frame's pyramid / mask block.
 struct OrbxTileDesc {
   int32_t l, tx, ty, f;
@@ -104,10 +106,10 @@ constexpr int orbx_fast3_tile_h(int nms_radius) {
 // tile geometry of the blur kernel
 #define ORBX_BLUR_TW 64
 #define ORBX_BLUR_TH 16
-// tile geometry of the register-streaming separable blur (k_blur2): 4 waves x 16 rows
-#define ORBX_BLUR2_TW 248
-#define ORBX_BLUR2_TH 64
-int orbx_blur2_rows_per_wave();  // 16 or 32; tile height of k_blur2 = 4x this
+// register-streaming separable blur (orbx_blur.hip): a wave owns a strip of 256 pixels (one aligned
+// 256-byte segment per row) over a band of at most ORBX_BLUR3_RH rows
+#define ORBX_BLUR3_TW 256
+#define ORBX_BLUR3_RH 64
 // pyramid kernel: a wave owns 256 x 8 pixels (level 0 and the levels resized through 8-byte
 // windows) or 256 x 4, a workgroup four times that; OrbxTileDesc::f carries the rows per wave
 #define ORBX_PYR2_TW 256
@@ -142,8 +144,8 @@ hipError_t orbx_launch_pyramid2(hipStream_t s, const OrbxTileDesc* d_tiles, int 
                                 const OrbxResizeTap* d_taps, uint8_t* d_pyr);
 hipError_t orbx_launch_blur(hipStream_t s, const OrbxPlan& plan, const OrbxTileMap& tm, int n_frames,
                             const uint8_t* d_src, uint8_t* d_dst, int first_level, int kind);
-// d_tiles: tiles of ONE frame for 248 x (4*rows_per_wave) strips
-hipError_t orbx_launch_blur2(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int n_frames,
+// d_tiles: strip table of ONE frame (level, strip, first row, rows)
+hipError_t orbx_launch_blur3(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int n_frames,
                              const uint8_t* d_src, uint8_t* d_dst, int first_level);
 // d_tiles: n_tiles OrbxTileDesc in band-major order (orbx_api.cpp: build_fast_tiles, tile height
 // orbx_fast3_tile_h(fp.nms_radius)); d_scores: optional dense u16 score map of ONE frame (stage operator)

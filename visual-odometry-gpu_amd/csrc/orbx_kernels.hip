@@ -314,168 +314,7 @@ __global__ __launch_bounds__(256) void k_blur(OrbxPlan plan, OrbxTileMap tm, con
   if (gy < L.h && gx < L.pitch) *reinterpret_cast<uint32_t*>(out + (size_t)gy * L.pitch + gx) = packed;
 }
 
-// ---------------------------------------------------------------------------
-// 2b. separable 5x5 blur, second generation: NO LDS, NO barriers.
-//   One wavefront owns a 256-pixel-wide column strip (64 lanes x one aligned
-//   dword = 4 pixels) and walks BL2_RH+4 rows top to bottom:
-//     * each row is one coalesced 256-byte global load per wave; the left /
-//       right neighbour dwords come from the adjacent lanes with DPP
-//       wave_shr/wave_shl (lane 0 / lane 63 fetch one extra dword);
-//     * the horizontal [1 4 6 4 1] pass runs on packed 16-bit lanes
-//       (v_perm_b32 gathers the shifted byte pairs, v_pk_add/mad_u16 does two
-//       pixels per op); the five most recent H rows live in registers, so the
-//       vertical pass needs no memory at all;
-//     * rne(S/256) is (S + 127 + ((S>>8)&1)) >> 8 on packed lanes, repacked
-//       to one dword store per lane per row.
-//   REFLECT_101: rows by index; columns by patching the dword that holds the
-//   image's last pixel (and the virtual dword left of x = 0) with v_perm.
-#define BL2_TW 248   // productive pixels per wave row: lanes 1..62 (lanes 0 and 63 are halo-only)
-
-__device__ __forceinline__ uint32_t pk_mad(uint32_t a, unsigned short m, uint32_t c) {
-  const us2_t mm = {m, m};
-  return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) * mm + __builtin_bit_cast(us2_t, c)));
-}
-// a * k + c on both 16-bit lanes with the packed multiplier in a register the optimiser cannot see
-// through (pk_opaque): a literal 4 would be strength-reduced to shift + add, two instructions
-// where v_pk_mad_u16 is one
-__device__ __forceinline__ uint32_t pk_mad_r(uint32_t a, uint32_t k, uint32_t c) {
-  return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) * __builtin_bit_cast(us2_t, k) +
-                                              __builtin_bit_cast(us2_t, c)));
-}
-__device__ __forceinline__ uint32_t pk_opaque(uint32_t k) {
-  asm volatile("" : "+s"(k));
-  return k;
-}
-// round-half-even of S/256 on both 16-bit lanes: the result is the HIGH byte of each lane of
-// S + 127 + ((S >> 8) & 1)  (no final shift: one v_perm gathers the four high bytes of the even
-// and odd pixel pairs straight into the output dword)
-// (S <= 255 * 256 per lane, so the sums never carry into the neighbouring lane and plain 32-bit
-// operations do: shift, and, one three-input add)
-__device__ __forceinline__ uint32_t pk_rne8_hi(uint32_t S) {
-  return S + 0x007f007fu + ((S >> 8) & 0x00010001u);
-}
-
-// wave-uniform REFLECT_101 on scalars (row index)
-__device__ __forceinline__ int reflect101_s(int p, int len) {
-  p = p < 0 ? -p : p;
-  p = p >= len ? 2 * len - p - 2 : p;
-  p = p < 0 ? 0 : p;
-  return p >= len ? len - 1 : p;
-}
-
-// the rows of one wave's strip: horizontal pass per incoming row, vertical pass over the five
-// most recent H rows.  PATCH: the wave holds x = 0 or the image's last pixel and applies the
-// REFLECT_101 column selectors (three extra v_perm per row); interior waves skip them.
-template <int RH, bool PATCH>
-__device__ __forceinline__ void blur2_rows(const uint32_t (&Craw)[RH + 4], uint32_t selL, uint32_t selC, uint32_t selR,
-                                           uint32_t vmask, __amdgpu_buffer_rsrc_t rout, uint32_t voff_st, int ya,
-                                           int h, int pitch) {
-  uint32_t he[5], ho[5];
-  const uint32_t k4 = pk_opaque(0x00040004u), k6 = pk_opaque(0x00060006u);
-#pragma unroll
-  for (int i = 0; i < RH + 4; i++) {
-    const uint32_t C0 = Craw[i];
-    const uint32_t Ld = __builtin_amdgcn_update_dpp(C0, C0, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
-    const uint32_t Lw = PATCH ? __builtin_amdgcn_perm(C0, Ld, selL) : Ld;
-    const uint32_t C = PATCH ? __builtin_amdgcn_perm(C0, Lw, selC) : C0;
-    const uint32_t Rd = __builtin_amdgcn_update_dpp(C, C, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
-    const uint32_t Rw = PATCH ? __builtin_amdgcn_perm(C0, Rd, selR) : Rd;
-
-    // byte pairs (16-bit lanes): perm bytes 0-3 = 2nd argument, 4-7 = 1st
-    const uint32_t A = __builtin_amdgcn_perm(C, Lw, 0x0c040c02u);   // (L.b2, C.b0)
-    const uint32_t B = __builtin_amdgcn_perm(C, Lw, 0x0c050c03u);   // (L.b3, C.b1)
-    const uint32_t Cc = __builtin_amdgcn_perm(C, C, 0x0c020c00u);   // (C.b0, C.b2)
-    const uint32_t D = __builtin_amdgcn_perm(C, C, 0x0c030c01u);    // (C.b1, C.b3)
-    const uint32_t E = __builtin_amdgcn_perm(Rw, C, 0x0c040c02u);   // (C.b2, R.b0)
-    const uint32_t F = __builtin_amdgcn_perm(Rw, C, 0x0c050c03u);   // (C.b3, R.b1)
-    he[i % 5] = pk_mad_r(pk_add(B, D), k4, pk_mad_r(Cc, k6, pk_add(A, E)));   // pixels 0,2
-    ho[i % 5] = pk_mad_r(pk_add(Cc, E), k4, pk_mad_r(D, k6, pk_add(B, F)));   // pixels 1,3
-    if (i >= 4) {
-      const int y = ya + i - 4;
-      // window rows y-2..y+2 are slots (i-4)%5 .. i%5
-      const uint32_t te = pk_rne8_hi(pk_mad_r(pk_add(he[(i - 3) % 5], he[(i - 1) % 5]), k4,
-                                              pk_mad_r(he[(i - 2) % 5], k6, pk_add(he[(i - 4) % 5], he[i % 5]))));
-      const uint32_t to = pk_rne8_hi(pk_mad_r(pk_add(ho[(i - 3) % 5], ho[(i - 1) % 5]), k4,
-                                              pk_mad_r(ho[(i - 2) % 5], k6, pk_add(ho[(i - 4) % 5], ho[i % 5]))));
-      // bytes: px0 = te lane0 high byte, px1 = to lane0 high, px2 = te lane1 high, px3 = to lane1 high
-      const uint32_t out = __builtin_amdgcn_perm(to, te, 0x07030501u);
-      // (interior waves lie wholly left of the image's last dword: nothing to mask)
-      if (y < h) __builtin_amdgcn_raw_buffer_store_b32(PATCH ? (out & vmask) : out, rout, voff_st, y * pitch, 0);
-    }
-  }
-}
-
-template <int RH>
-__global__ __launch_bounds__(256) void k_blur2(const OrbxTileDesc* __restrict__ tiles, int frame_bytes,
-                                               const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                               int first_level) {
-  const OrbxTileDesc d = tiles[blockIdx.x];  // one scalar load instead of decoding through the plan
-  struct {
-    int w, h, pitch;
-  } L = {d.w, d.h, d.pitch};
-  const int l = d.l, tx = d.tx, ty = d.ty;
-  const int f = blockIdx.y;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: row math runs on the SALU
-  const int x = tx * BL2_TW - 4 + lane * 4;  // lane 0 holds the dword left of the strip
-  const int ya = ty * (4 * RH) + wave * RH;
-  if (ya >= L.h) return;  // whole wave
-  const int pitch = L.pitch, h = L.h;
-  // Buffer descriptors over the level image: the (scalar) row base goes in the
-  // scalar offset, the lane's x in the vector offset; lanes whose x is outside
-  // [0, pitch) use an out-of-range vector offset, so the hardware range check
-  // zero-fills their loads and drops their stores -- no exec-mask juggling, no
-  // 64-bit per-lane address arithmetic.
-  const size_t level_off = (size_t)f * frame_bytes + d.img_off;
-  const __amdgpu_buffer_rsrc_t rin =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src) + level_off, 0, pitch * h, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(dst + level_off, 0, pitch * h, 0x00020000);
-  const uint32_t voff_ld = (x >= 0 && x < pitch) ? (uint32_t)x : 0xffffffffu;
-  const uint32_t voff_st = (lane >= 1 && lane <= 62 && x < pitch) ? (uint32_t)x : 0xffffffffu;
-
-  if (l < first_level) {  // pass-through copy
-#pragma unroll 4
-    for (int i = 0; i < RH; i++) {
-      const int y = ya + i;
-      if (y < h) {
-        const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(rin, voff_st, y * pitch, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(v, rout, voff_st, y * pitch, 0);
-      }
-    }
-    return;
-  }
-
-  // every row of the strip is requested before the first one is used
-  uint32_t Craw[RH + 4];
-#pragma unroll
-  for (int i = 0; i < RH + 4; i++)
-    Craw[i] = __builtin_amdgcn_raw_buffer_load_b32(rin, voff_ld, reflect101_s(ya - 2 + i, h) * pitch, 0);
-
-  // column REFLECT_101 as per-lane v_perm selectors (identity except in the lane
-  // holding x = 0 and the lane holding the image's last pixel)
-  const int e4 = (L.w - 1) & ~3;    // x of the dword holding the last pixel
-  const int rbyte = (L.w - 1) & 3;  // its position inside that dword
-  const bool edge = (x == e4);
-  // Lw = perm(C, Ldpp, selL): bytes 0-3 = Ldpp, 4-7 = C.   x=-1 <- x=1, x=-2 <- x=2
-  const uint32_t selL = x == 0 ? 0x05060c0cu : 0x03020100u;
-  // C' = perm(C, Lw, selC): bytes 0-3 = Lw, 4-7 = C
-  const uint32_t selC_e = rbyte == 3 ? 0x07060504u : rbyte == 2 ? 0x05060504u : rbyte == 1 ? 0x03040504u : 0x07020304u;
-  const uint32_t selC = edge ? selC_e : 0x07060504u;
-  // Rw = perm(C0, Rdpp, selR): bytes 0-3 = Rdpp, 4-7 = C0 (the unpatched edge dword)
-  const uint32_t selR_e = rbyte == 3 ? 0x0c0c0506u : rbyte == 2 ? 0x0c0c0c04u : 0x0c0c0c0cu;
-  const uint32_t selR = edge ? selR_e : 0x03020100u;
-  // output bytes at x >= w are written as zero (padding stays zero)
-  const int nvalid = L.w - x;
-  const uint32_t vmask = nvalid >= 4 ? 0xffffffffu : nvalid <= 0 ? 0u : ((1u << (8 * nvalid)) - 1u);
-
-  // only the waves that hold x = 0 or the image's last pixel need the column patches
-  const int x_lo = tx * BL2_TW - 4, x_hi = x_lo + 4 * 63;
-  const bool patch = (x_lo <= 0) || (e4 >= x_lo && e4 <= x_hi);  // wave-uniform
-  if (patch)
-    blur2_rows<RH, true>(Craw, selL, selC, selR, vmask, rout, voff_st, ya, h, pitch);
-  else
-    blur2_rows<RH, false>(Craw, selL, selC, selR, vmask, rout, voff_st, ya, h, pitch);
-}
+// (2b. register-streaming separable blur: orbx_blur.hip)
 
 // (3. FAST-n segment test + score + NMS: orbx_fast.hip)
 
@@ -1787,26 +1626,6 @@ hipError_t orbx_launch_blur(hipStream_t s, const OrbxPlan& plan, const OrbxTileM
                             const uint8_t* d_src, uint8_t* d_dst, int first_level, int kind) {
   dim3 grid(tm.begin[plan.nlevels], n_frames);
   hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, s, plan, tm, d_src, d_dst, first_level, kind);
-  return ORBX_LAUNCH_CHECK();
-}
-
-int orbx_blur2_rows_per_wave() {
-  static const int v = [] {
-    const char* e = getenv("ORBX_BLUR2_RH");  // 16 (default) or 32 rows per wavefront
-    return (e && atoi(e) == 32) ? 32 : 16;
-  }();
-  return v;
-}
-
-// separable blur, register-streaming kernel; the tile table is built for 248 x (4*rows_per_wave) strips
-hipError_t orbx_launch_blur2(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int n_frames,
-                             const uint8_t* d_src, uint8_t* d_dst, int first_level) {
-  if (n_tiles <= 0) return hipSuccess;
-  dim3 grid(n_tiles, n_frames);
-  if (orbx_blur2_rows_per_wave() == 32)
-    hipLaunchKernelGGL(k_blur2<32>, grid, dim3(256), 0, s, d_tiles, frame_bytes, d_src, d_dst, first_level);
-  else
-    hipLaunchKernelGGL(k_blur2<16>, grid, dim3(256), 0, s, d_tiles, frame_bytes, d_src, d_dst, first_level);
   return ORBX_LAUNCH_CHECK();
 }
 
