@@ -6,19 +6,26 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1], batched as configs[2]): KITTI-shaped
-1241x376 8-bit frames, 8 pyramid levels, scale 1.2, 1000 features, FAST-9
-threshold 20, 3x3 NMS, Harris top-N, orientation patch 31, rotated BRIEF-256,
-5x5 Gaussian blur on every level.  A "step" = one pass of the whole path over
-one batch of --batch (default 64) synthetic frames that are already resident
-in HBM; results stay resident in HBM too (D2H-inclusive rate is reported
-separately as `fps_with_d2h`, it is never `value`).
+Workload (BASELINE.json configs[1], batched as configs[2]): KITTI-shaped 1241x376 8-bit frames,
+8 pyramid levels, scale 1.2, 1000 features, FAST-9 threshold 20, 3x3 NMS, Harris top-N, orientation
+patch 31, rotated BRIEF-256, 5x5 Gaussian blur on every level.  A "step" = one pass of the whole
+path over one batch of --batch (default 64) synthetic frames that are already resident in HBM; the
+steps rotate over --rotate (default 4) DISTINCT resident batches.  Results stay resident in HBM too
+(the D2H-inclusive rate is reported beside it as `fps_with_d2h`, it is never `value`).
 
-Frames are independent, so ranks shard the stream with NO data-path collective
-(weak scaling: every rank processes its own batch); torch.distributed (RCCL) is
-used only for the barrier, the max-over-ranks time and a result checksum.
+Frames are independent, so ranks shard the stream with NO data-path collective (weak scaling: every
+rank processes its own batches); torch.distributed (RCCL) is used only for the barrier, the
+max-over-ranks time and a result checksum.
+
+--stream-frames F (BASELINE.json configs[3]): a synthetic KITTI stream of 8*F frames is split over
+the ranks in contiguous blocks (shard.split_stream), each rank keeps its block resident in HBM and
+walks it once in --batch-frame batches (distinct inputs every step); the all-reduced checksum is the
+same for every world size.
+
+Only the `cpu_baseline` / `parity` legs touch oracle/ (the checker); the timed path is liborbx.so.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -31,10 +38,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# HBM bytes per launch (KITTI workload, batch 64) from separate rocprofv3 --pmc passes,
-# see profiles/r01/pmc_traffic.md for the raw counters and the correction applied
-PMC_TRAFFIC = {"k_blur": 209.4e6, "k_fast_nms": 28.4e6, "k_fast_nms_full_work": 79.3e6}
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0      # same guide: measured float4 copy
+VALU_CLOCK_GHZ = 2.4       # same guide: max clock; one wave64 VALU instruction holds its SIMD for 4 clocks
+N_SIMD = 1024              # 256 CUs x 4
+PMC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_counters.json")
 
 
 def stream_a(n, first=0):
@@ -53,6 +61,24 @@ def stream_a(n, first=0):
     return out
 
 
+def stream_a_device(torch, first, n, device):
+    """The same recipe generated on the GPU (a per-frame seeded torch generator instead of numpy's):
+    8000 frames take ~1 s instead of ~80 s of host time.  Frame i depends on i only, so any sharding
+    of the stream sees the same frames."""
+    import oracle_lib as O
+
+    base = [torch.from_numpy(O.load_kitti(k)).to(device).to(torch.int16) for k in (0, 1)]
+    out = torch.empty((n,) + tuple(base[0].shape), dtype=torch.uint8, device=device)
+    g = torch.Generator(device=device)
+    for j in range(n):
+        i = first + j
+        g.manual_seed(1000 + i)
+        noise = torch.round(torch.randn(base[0].shape, generator=g, device=device) * 2.0).to(torch.int16)
+        img = torch.roll(base[i & 1], shifts=((3 * i) % 17, (5 * i) % 11), dims=(0, 1)) + noise
+        out[j] = img.clamp_(0, 255).to(torch.uint8)
+    return out
+
+
 def stream_b(n, h, w, first=0):
     """SURVEY.md §8(d) stream B: synthetic frames of any resolution."""
     out = np.empty((n, h, w), np.uint8)
@@ -67,7 +93,27 @@ def stream_b(n, h, w, first=0):
     return out
 
 
-def cpu_baseline(frames, params_kw, budget_s=12.0, max_frames=4096):
+def host_threads():
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    return max(1, min(ncores, 32))
+
+
+def oracle_results(frames, params_kw):
+    """The oracle on every frame (frame-parallel over the host cores; ctypes releases the GIL)."""
+    import concurrent.futures as cf
+
+    import oracle_lib as O
+
+    op = O.gpu_params(**params_kw)
+    O.lib()
+    with cf.ThreadPoolExecutor(host_threads()) as ex:
+        return list(ex.map(lambda f: O.detect_and_compute_gpu(f, op), frames))
+
+
+def cpu_baseline(frames, params_kw, budget_s=10.0, max_frames=4096):
     """The CPU oracle (a port of orb_cpu.cpp + the orb.cpp orchestrator intent)
     timed single-threaded on a bounded sample of the same workload."""
     import oracle_lib as O
@@ -86,15 +132,10 @@ def cpu_baseline(frames, params_kw, budget_s=12.0, max_frames=4096):
            "sample": "%d stream-A frames 1241x376 (the step's batch, cycled), same parameters, "
                      "oracle/liborb_oracle.so single thread, %.1f s" % (done, dt)}
     # the same oracle frame-parallel over the host cores this process may use (the
-    # reference itself is single-threaded, so this is the most a frame-parallel CPU run of it could
-    # give); ctypes releases the GIL during the call
+    # reference itself is single-threaded, so this is the most a frame-parallel CPU run of it could give)
     import threading
 
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncores = os.cpu_count() or 1
-    nthr = max(1, min(ncores, 32))
+    nthr = host_threads()
     counts = [0] * nthr
     stop = time.perf_counter() + budget_s / 2
 
@@ -114,19 +155,54 @@ def cpu_baseline(frames, params_kw, budget_s=12.0, max_frames=4096):
     dt2 = time.perf_counter() - t1
     out["all_cores"] = {"value": sum(counts) / dt2, "unit": "frames/s", "cores": nthr,
                         "sample": "%d frames over %d threads, %.1f s" % (sum(counts), nthr, dt2)}
+    # BASELINE.json configs[0] / BASELINE.md §3: orb_cpu.cpp detectAndCompute on 000000.png, CPU-flavour
+    # defaults (threshold 50, patch 9, cap 3000, ONE level), single thread
+    k0 = O.load_kitti(0)
+    O.detect_and_compute_cpu(k0)
+    t2, n0 = time.perf_counter(), 0
+    while time.perf_counter() - t2 < 2.0:
+        kps0 = O.detect_and_compute_cpu(k0)[0]
+        n0 += 1
+    dt3 = time.perf_counter() - t2
+    out["config0_orb_cpu_000000"] = {"value": n0 / dt3, "unit": "frames/s", "cores": 1, "ms_per_frame": dt3 / n0 * 1e3,
+                                     "keypoints": int(len(kps0)),
+                                     "sample": "%d runs of the oracle's ORBCPU::detectAndCompute port on 000000.png "
+                                               "(1241x376, 1 level, t=50, cap 3000)" % n0}
     return out
+
+
+def kernel_source_sha():
+    """Hash of the kernel sources: PMC counters from profiles/ are used only for the build they describe."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "visual-odometry-gpu_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".inc", ".cpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(path):
+    """Per-kernel counters of separate rocprofv3 --pmc passes (tools/pmc_collect.sh -> pmc_counters.json)."""
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if d.get("source_sha") != kernel_source_sha():
+        return None  # counters of another build say nothing about this one
+    return d
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--rotate", type=int, default=4, help="distinct resident input batches the steps rotate over")
     ap.add_argument("--workload", default="kitti", choices=["kitti", "1080p"])
+    ap.add_argument("--stream-frames", type=int, default=0,
+                    help="config 3: a stream of 8*F frames split over the ranks, each rank walks its block once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-stage-events", action="store_true",
-                    help="do not record per-stage HIP events inside the timed region (diagnostic)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl == RCCL; gloo only to rehearse N>1 on a one-GPU box)")
     ap.add_argument("--all-ranks-on-device0", action="store_true",
@@ -134,8 +210,10 @@ def main():
     ap.add_argument("--only-timed", action="store_true",
                     help="skip every extra pass (full-work FAST, D2H, single-frame, matcher): for rocprofv3 runs whose "
                          "per-kernel averages must describe the timed configuration only")
-    ap.add_argument("--pmc-traffic", type=float, default=None,
-                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
+    ap.add_argument("--full-work", action="store_true",
+                    help="run the TIMED region with the FAST early exit off (for rocprofv3 runs of the full-work kernel)")
+    ap.add_argument("--pmc-file", default=PMC_FILE,
+                    help="per-kernel counters from separate rocprofv3 --pmc passes of THIS build (tools/pmc_collect.sh)")
     args = ap.parse_args()
 
     import torch
@@ -152,9 +230,10 @@ def main():
     if args.all_ranks_on_device0:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
     pkg = importlib.import_module("visual-odometry-gpu_amd")
@@ -162,219 +241,310 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
     B = args.batch
+    stream_mode = args.stream_frames > 0
     if args.workload == "kitti":
         H, W = 376, 1241
         pk = dict(nfeatures=1000, nlevels=8, scale_factor=1.2, threshold=20, n=9, nms_window=3, patch_size=31,
                   blur_levels=2, blur_kind=0)
-        frames = stream_a(B, first=pkg.shard.frame_range(rank, world, B)[0])
-        wl = "KITTI-shaped 1241x376 u8, 8 levels s=1.2, 1000 features, FAST-9 t=20, NMS 3x3, Harris top-N, blur5 all levels, BRIEF-256; batch=%d frames/step/GPU resident in HBM (stream A)" % B
+        wl = ("KITTI-shaped 1241x376 u8, 8 levels s=1.2, 1000 features, FAST-9 t=20, NMS 3x3, Harris top-N, blur5 all "
+              "levels, BRIEF-256; batch=%d frames/step/GPU resident in HBM (stream A)" % B)
     else:
         H, W = 1080, 1920
         pk = dict(nfeatures=4000, nlevels=12, scale_factor=1.2, threshold=20, n=9, nms_window=3, patch_size=31,
                   blur_levels=2, blur_kind=0)
-        frames = stream_b(B, H, W, first=pkg.shard.frame_range(rank, world, B)[0])
         wl = "1920x1080 u8, 12 levels, 4000 features, Harris+NMS; batch=%d (stream B)" % B
+
+    # ---- inputs, resident in HBM before anything is timed
+    if stream_mode:
+        total = 8 * args.stream_frames
+        first, last = pkg.shard.split_stream(total, rank, world)
+        d_all = stream_a_device(torch, first, last - first, dev)
+        nlocal = last - first
+        nbatches = (nlocal + B - 1) // B
+        batches = [(d_all[i * B:min((i + 1) * B, nlocal)], min(B, nlocal - i * B)) for i in range(nbatches)]
+        frames0 = batches[0][0].cpu().numpy()
+        steps = args.steps if args.steps is not None else nbatches
+        wl += "; stream mode: %d frames total, rank block %d" % (total, nlocal)
+    else:
+        R = max(1, args.rotate)
+        steps = args.steps if args.steps is not None else 20
+        f0 = pkg.shard.frame_range(rank, world, R * B)[0]
+        if args.workload == "kitti":
+            host = [stream_a(B, first=f0 + r * B) for r in range(R)]
+        else:
+            host = [stream_b(B, H, W, first=f0 + r * B) for r in range(R)]
+        batches = [(torch.from_numpy(h).to(dev), B) for h in host]
+        frames0 = host[0]
+    torch.cuda.synchronize()
 
     p = pkg.default_params("gpu", max_width=W, max_height=H, max_batch=B, device=local_rank, **pk)
     ctx = pkg.Context(p)
     plan = ctx.plan(W, H)
+    cap = plan["out_capacity"]
     pyr_px = int((plan["level_w"].astype(np.int64) * plan["level_h"]).sum())
-    d_frames = torch.from_numpy(frames).cuda()
-    torch.cuda.synchronize()
-
-    grp = pkg.shard.Group(world, device=torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None)
+    grp = pkg.shard.Group(world, device=dev if args.dist_backend == "nccl" else None)
 
     def barrier():
         torch.cuda.synchronize()
         grp.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        ctx.batch_device(d_frames.data_ptr(), B, W, H)
+    def submit(i):
+        t, n = batches[i % len(batches)]
+        ctx.batch_device(t.data_ptr(), n, W, H)
+        return n
+
+    if args.full_work:
+        ctx.set_fast_early_exit(False)
+    for i in range(args.warmup):
+        submit(i)
         ctx.wait()
 
-    for _ in range(args.warmup):
-        step()
-
-    # timed region: exactly K steps.  HIP events (on the context's stream) bracket
-    # only the two roofline kernels, blur and fast+nms, so that the event records
-    # do not inflate `value` (7 % with events around all seven stages).
-    ctx.enable_stage_timing(0 if args.no_stage_events else 2)
-    roof_ms = {"blur": 0.0, "fast_nms": 0.0}
+    # ---- timed region: exactly `steps` steps, enqueued back to back on the context's stream, one wait at
+    # the end.  HIP events on that stream bracket only the two roofline kernels, blur and fast+nms (event
+    # records around all seven stages would inflate `value` by ~7 %).
+    ctx.enable_stage_timing(2)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        # steps are enqueued back to back on the context's stream (each has its own
-        # event set); one wait at the end, then the barrier + synchronize
-        ctx.batch_device(d_frames.data_ptr(), B, W, H)
+    nframes = 0
+    for i in range(steps):
+        nframes += submit(i)
     ctx.wait()
     barrier()
     dt = time.perf_counter() - t0
     dt = grp.max_float(dt)
+    nframes_all = grp.sum_int(nframes)
     fast_tiles = ctx.fast_tile_counts()  # (did the full work, all) of the last timed step
-    if not args.no_stage_events:
-        nread = min(args.steps, 64)
-        for back in range(nread):
-            lt = ctx.last_stage_times(back)
-            roof_ms["blur"] += lt["blur"] / nread
-            roof_ms["fast_nms"] += lt["fast_nms"] / nread
-    # full per-stage breakdown from a separate, untimed pass
-    nb = max(1, min(args.steps, 10))
+    nread = min(steps, 64)
+    roof_ms = {"blur": 0.0, "fast_nms": 0.0}
+    for back in range(nread):
+        lt = ctx.last_stage_times(back)
+        for k in roof_ms:
+            roof_ms[k] += lt[k] / nread
+
+    # ---- stream mode: the checksum of the whole pass (independent of the sharding)
+    stream_info = None
+    if stream_mode:
+        ctx.enable_stage_timing(0)
+        kp_local, cs_local = 0, 0
+        for i in range(len(batches)):
+            n = submit(i)
+            res = ctx.batch_fetch(0, n, cap)
+            kp_local += int(res["counts"].sum())
+            cs_local = (cs_local + pkg.shard.descriptor_checksum(res["counts"], res["desc"])) & 0x7FFFFFFFFFFFFFFF
+        stream_info = {"total_frames": 8 * args.stream_frames, "frames_this_rank": int(sum(b[1] for b in batches)),
+                       "batches_this_rank": len(batches), "keypoints": grp.sum_int(kp_local),
+                       "desc_checksum": grp.sum_checksum(cs_local),
+                       "frames_per_s_strong": None}
+        if steps == len(batches):  # the timed region was exactly one pass over every rank's block
+            stream_info["frames_per_s_strong"] = stream_info["total_frames"] / dt
+
+    # ---- untimed passes: all-stage breakdown with the timed configuration, then with every FAST tile working
+    nb = max(1, min(steps, 10))
 
     def breakdown():
         ctx.enable_stage_timing(1)
         acc = {k: 0.0 for k in pkg.orbx.STAGE_NAMES}
-        for _ in range(nb):
-            step()
+        for i in range(nb):
+            submit(i)
+            ctx.wait()
             for k, v in ctx.last_stage_times().items():
                 acc[k] += v / nb
         ctx.enable_stage_timing(0)
         return acc
 
-    stage_ms = breakdown() if not args.only_timed else {k: 0.0 for k in pkg.orbx.STAGE_NAMES}
-    full_ms = dict(stage_ms)
-    if not args.only_timed:
-        # the FAST kernel with its early exit switched off: every tile does the full work
+    zero = {k: 0.0 for k in pkg.orbx.STAGE_NAMES}
+    stage_ms = breakdown() if not args.only_timed else dict(zero)
+    full_ms, full_tiles = dict(stage_ms), fast_tiles
+    if not args.only_timed and not args.full_work:
         ctx.set_fast_early_exit(False)
-        step()
+        submit(0)
+        ctx.wait()
         full_ms = breakdown()
+        full_tiles = ctx.fast_tile_counts()
         ctx.set_fast_early_exit(True)
-    if args.no_stage_events:
-        roof_ms = {k: stage_ms[k] for k in roof_ms}
+    if args.full_work:
+        full_ms = dict(stage_ms) if not args.only_timed else dict(zero, fast_nms=roof_ms["fast_nms"], blur=roof_ms["blur"])
+    ctx.enable_stage_timing(0)
 
-    # D2H-inclusive rate (reported beside, never as `value`)
-    cap = plan["out_capacity"]
-    nd2h = 1 if args.only_timed else max(1, min(args.steps, 5))
-    t1 = time.perf_counter()
-    for _ in range(nd2h):
-        ctx.batch_device(d_frames.data_ptr(), B, W, H)
-        res = ctx.batch_fetch(0, B, cap)
-    dt_d2h = (time.perf_counter() - t1) / nd2h
+    # ---- results of batch 0 (for the checksum and the oracle comparison)
+    n0 = submit(0)
+    res0 = ctx.batch_fetch(0, n0, cap)
+    kp0 = int(res0["counts"].sum())
+    cs0 = pkg.shard.descriptor_checksum(res0["counts"], res0["desc"])
 
-    # informational (never `value`): two contexts, each with its own stream and pools, fed alternately --
-    # the latency-bound tail of one step (selection, describe) overlaps the front of the next one
-    two_ctx_fps = None
-    if rank == 0 and not args.only_timed:
-        with pkg.Context(p) as ctx2:
+    # ---- D2H-inclusive rate (reported beside `value`, never as it): the result block of batch i is copied on
+    # the context's copy stream while batch i+1 runs (orbx_batch_prefetch / orbx_batch_fetch_previous)
+    fps_d2h = fps_d2h_blocking = None
+    if not args.only_timed:
+        nd = max(steps, 10)
+        submit(0)
+        ctx.batch_prefetch()
+        t1 = time.perf_counter()
+        done = 0
+        for i in range(1, nd + 1):
+            n = submit(i)
+            r_prev = ctx.batch_fetch(0, batches[(i - 1) % len(batches)][1], cap, previous=True)
+            done += len(r_prev["counts"])
+            ctx.batch_prefetch()
+        ctx.wait()
+        fps_d2h = world * done / (time.perf_counter() - t1)
+        t1 = time.perf_counter()
+        done = 0
+        for i in range(5):
+            n = submit(i)
+            ctx.batch_fetch(0, n, cap)
+            done += n
+        fps_d2h_blocking = world * done / (time.perf_counter() - t1)
+
+    # ---- informational extras (never `value`)
+    two_ctx_fps = lk = single = None
+    match_ms, n_matches = 0.0, 0
+    if rank == 0 and not args.only_timed and not stream_mode:
+        with pkg.Context(p) as ctx2:  # two contexts fed alternately: the tail of one step overlaps the next one's front
             pair = (ctx, ctx2)
+            t_, n_ = batches[0]
             for i in range(4):
-                pair[i & 1].batch_device(d_frames.data_ptr(), B, W, H)
+                pair[i & 1].batch_device(t_.data_ptr(), n_, W, H)
             ctx.wait()
             ctx2.wait()
-            nst = max(args.steps, 10)
+            nst = max(steps, 10)
             t5 = time.perf_counter()
             for i in range(nst):
-                pair[i & 1].batch_device(d_frames.data_ptr(), B, W, H)
+                pair[i & 1].batch_device(batches[i % len(batches)][0].data_ptr(), n_, W, H)
             ctx.wait()
             ctx2.wait()
-            two_ctx_fps = B * nst / (time.perf_counter() - t5)
-
-    # next row, informational: Hamming 2-NN + ratio test of every consecutive
-    # frame pair of the batch, on the device-resident descriptors (not part of `value`)
-    match_ms, n_matches = 0.0, 0
-    if not args.only_timed and B > 1:
-        ctx.batch_device(d_frames.data_ptr(), B, W, H)
-        ctx.wait()
-        t3 = time.perf_counter()
-        for _ in range(5):
-            ctx.batch_match_consecutive(0.8)
-        ctx.wait()
-        match_ms = (time.perf_counter() - t3) / 5 * 1e3
-        n_matches = len(ctx.batch_match_fetch(0, cap)[0])
-
-    # Lucas-Kanade tracking between consecutive frames, the reference's call shape
-    # (calcOpticalFlowPyrLK 21x21 / 3 levels / 30 it. / 0.01, feature_tracking.cpp:175-181): host frame in,
-    # tracked points out, synchronous; the previous frame's pyramid stays on the device (prev=None)
-    lk = None
-    if rank == 0 and not args.only_timed and B > 1:
-        kps0, _ = ctx.fast(frames[0], 20, 9, 3, 3000)
-        pts0 = kps0.astype(np.float32)
-        ctx.lk_track(frames[0], frames[1 % B], pts0)
-        nlk = 50
-        t4 = time.perf_counter()
-        tracked = 0
-        for i in range(nlk):
-            _, st_lk, _ = ctx.lk_track(None, frames[(i + 2) % B], pts0)
-            tracked += int(st_lk.sum())
-        lk_ms = (time.perf_counter() - t4) / nlk * 1e3
-        lk = {"ms_per_frame": lk_ms, "points": int(len(pts0)), "tracked_mean": tracked / nlk,
-              "what": "orbx_lk_track: next frame in (host), tracked points out, cached previous pyramid, synchronous"}
-
-    # per-frame host-in / host-out call (orbx_detect_and_compute, the reference's own call shape:
-    # H2D of the frame + the whole path + one D2H of the results + sync), BASELINE.json configs[1]
-    single = None
-    if rank == 0 and not args.only_timed:
+            two_ctx_fps = n_ * nst / (time.perf_counter() - t5)
+        if B > 1:
+            # next row: Hamming 2-NN + ratio test of consecutive frame pairs, device-resident
+            submit(0)
+            ctx.wait()
+            t3 = time.perf_counter()
+            for _ in range(5):
+                ctx.batch_match_consecutive(0.8)
+            ctx.wait()
+            match_ms = (time.perf_counter() - t3) / 5 * 1e3
+            n_matches = len(ctx.batch_match_fetch(0, cap)[0])
+            # Lucas-Kanade between consecutive frames, the reference's call shape (feature_tracking.cpp:175-181)
+            kps0, _ = ctx.fast(frames0[0], 20, 9, 3, 3000)
+            pts0 = kps0.astype(np.float32)
+            ctx.lk_track(frames0[0], frames0[1 % B], pts0)
+            nlk, tracked = 50, 0
+            t4 = time.perf_counter()
+            for i in range(nlk):
+                _, st_lk, _ = ctx.lk_track(None, frames0[(i + 2) % B], pts0)
+                tracked += int(st_lk.sum())
+            lk = {"ms_per_frame": (time.perf_counter() - t4) / nlk * 1e3, "points": int(len(pts0)),
+                  "tracked_mean": tracked / nlk,
+                  "what": "orbx_lk_track: next frame in (host), tracked points out, cached previous pyramid, synchronous"}
+        # per-frame host-in / host-out call (orbx_detect_and_compute, the reference's own call shape), configs[1]
         p1 = pkg.default_params("gpu", max_width=W, max_height=H, max_batch=1, device=local_rank, **pk)
         with pkg.Context(p1) as c1:
             for i in range(5):
-                c1.detect_and_compute(frames[i % B])
+                c1.detect_and_compute(frames0[i % B])
             n1 = 200 if args.workload == "kitti" else 50
             t2 = time.perf_counter()
             for i in range(n1):
-                r1 = c1.detect_and_compute(frames[i % B])
+                r1 = c1.detect_and_compute(frames0[i % B])
             dt1 = (time.perf_counter() - t2) / n1
             single = {"ms_per_frame": dt1 * 1e3, "frames_per_s": 1.0 / dt1, "keypoints": int(r1["count"]),
                       "what": "orbx_detect_and_compute: host frame in, host keypoints/descriptors out, synchronous"}
 
-    # result checksum: same answer on every run / rank layout (frames are rank-specific)
-    n_kp = grp.sum_int(int(res["counts"].sum()))
-    csum = grp.sum_checksum(pkg.shard.descriptor_checksum(res["counts"], res["desc"]))
+    n_kp = grp.sum_int(kp0)
+    csum = grp.sum_checksum(cs0)
 
     if rank == 0:
-        fps = world * B * args.steps / dt
-        # dominant kernel among the two roofline stages.  Algorithmic
-        # bytes: blur 2 B/px, FAST 1 B/px over all pyramid pixels.
-        alg = {"blur": 2.0 * pyr_px * B, "fast_nms": 1.0 * pyr_px * B}
-        dom = max(("blur", "fast_nms"), key=lambda k: roof_ms[k])
+        fps = nframes_all / dt
+        # ---- roofline.  Algorithmic bytes (SURVEY.md §8d / BASELINE.md §4): blur 2 B/px, FAST 1 B/px over all
+        # pyramid pixels; pyramid = level 0 read + every level written; per launch = per frame x batch.
+        alg = {"pyramid": (W * H + pyr_px) * B, "blur": 2.0 * pyr_px * B, "fast_nms": 1.0 * pyr_px * B}
+        pmc = load_pmc(args.pmc_file) if (args.workload == "kitti" and B == 64) else None
 
         def gbs(nbytes, ms):
             return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
 
-        achieved = gbs(alg[dom], roof_ms[dom])
-        both = gbs(alg["blur"] + alg["fast_nms"], roof_ms["blur"] + roof_ms["fast_nms"])
-        # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01/pmc_traffic.md):
-        # (FETCH_SIZE * c + WRITE_SIZE) * 1024, c = 1.35 calibrated on this access pattern
-        traffic = {"k_blur": PMC_TRAFFIC["k_blur"], "k_fast_nms": PMC_TRAFFIC["k_fast_nms"]}
+        def entry(name, nbytes, ms, pmc_key=None, extra=None):
+            e = {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": nbytes}
+            if nbytes:
+                a = gbs(nbytes, ms)
+                e.update({"achieved_GBps": a, "frac_of_8000": a / HBM_PEAK_GBS, "frac_of_6290_measured_copy": a / HBM_COPY_GBS})
+            c = (pmc or {}).get("kernels", {}).get(pmc_key or name)
+            if c:
+                e["valu_insts_per_launch"] = c.get("valu")
+                if c.get("valu"):
+                    e["valu_floor_ms"] = c["valu"] * 4 / N_SIMD / (VALU_CLOCK_GHZ * 1e9) * 1e3
+                e["hbm_traffic_bytes_per_launch"] = c.get("traffic_bytes")
+            if extra:
+                e.update(extra)
+            return e
+
+        work_frac = fast_tiles[0] / max(fast_tiles[1], 1)
+        kern = {
+            "pyramid": entry("pyramid", alg["pyramid"], stage_ms["pyramid"], "k_pyramid2"),
+            "blur": entry("blur", alg["blur"], roof_ms["blur"], "k_blur3"),
+            "fast_nms_full_work": entry("fast_nms", alg["fast_nms"], full_ms["fast_nms"], "k_fast3_full_work",
+                                        {"tiles_worked": full_tiles[0], "tiles": full_tiles[1]}),
+            "fast_nms_timed_region": entry("fast_nms", alg["fast_nms"] * work_frac, roof_ms["fast_nms"], "k_fast3",
+                                           {"tiles_worked": fast_tiles[0], "tiles": fast_tiles[1],
+                                            "note": "early exit on (production): bytes charged = tiles that worked / all tiles x 1 B/px"}),
+            "select": entry("select", 0, stage_ms["select"] + stage_ms["compact"] + stage_ms["harris"], "k_level_select"),
+            "describe": entry("describe", 0, stage_ms["describe"], "k_describe2"),
+        }
+        # headline: the slower of the two roofline kernels, FAST with every tile working
+        dom = "blur" if roof_ms["blur"] >= full_ms["fast_nms"] else "fast_nms_full_work"
+        dom_ms = kern[dom]["avg_launch_ms"]
+        achieved = gbs(kern[dom]["algorithmic_bytes_per_launch"], dom_ms)
+        both_full = gbs(alg["blur"] + alg["fast_nms"], roof_ms["blur"] + full_ms["fast_nms"])
+        both_timed = gbs(alg["blur"] + alg["fast_nms"] * work_frac, roof_ms["blur"] + roof_ms["fast_nms"])
         out = {
             "metric": "ORB detect+describe frames/sec (1241x376, 8 lvls)" if args.workload == "kitti"
                       else "ORB detect+describe frames/sec (1920x1080, 12 lvls)",
-            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong" if stream_mode else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": wl, "frames_per_step_per_gpu": B, "sharding": "frame-parallel, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_blur2" if dom == "blur" else "k_fast_nms2",
+            "config": {"workload": wl, "frames_per_step_per_gpu": B, "distinct_resident_batches": len(batches),
+                       "sharding": "frame-parallel, no data-path collective",
+                       "fast_early_exit": not args.full_work},
+            "roofline": {"bound": "hbm", "kernel": "k_blur3" if dom == "blur" else "k_fast3 (every tile working)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (args.pmc_traffic if args.pmc_traffic is not None else
-                                     (traffic["k_blur" if dom == "blur" else "k_fast_nms"]
-                                      if args.workload == "kitti" and B == 64 else None)),
-                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": roof_ms[dom],
-                         "note": "k_fast_nms2 runs with its provable early exit in the timed region; "
-                                 "full_work below is the same kernel with every tile doing the full work",
-                         "blur": {"achieved": gbs(alg["blur"], roof_ms["blur"]),
-                                  "frac": gbs(alg["blur"], roof_ms["blur"]) / HBM_PEAK_GBS,
-                                  "avg_launch_ms": roof_ms["blur"]},
-                         "fast_nms": {"achieved": gbs(alg["fast_nms"], roof_ms["fast_nms"]),
-                                      "frac": gbs(alg["fast_nms"], roof_ms["fast_nms"]) / HBM_PEAK_GBS,
-                                      "avg_launch_ms": roof_ms["fast_nms"]},
-                         "fast_nms_full_work": {"achieved": gbs(alg["fast_nms"], full_ms["fast_nms"]),
-                                                "frac": gbs(alg["fast_nms"], full_ms["fast_nms"]) / HBM_PEAK_GBS,
-                                                "avg_launch_ms": full_ms["fast_nms"]},
-                         "blur_plus_fast": {"achieved": both, "frac": both / HBM_PEAK_GBS,
-                                            "algorithmic_bytes_per_step": alg["blur"] + alg["fast_nms"]}},
+                         "traffic": kern[dom].get("hbm_traffic_bytes_per_launch"),
+                         "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes_per_launch"],
+                         "avg_launch_ms": dom_ms,
+                         "residency": "batch %d: pools %.0f MB, %s the 256 MiB Infinity Cache" % (
+                             B, 2 * 1.05 * pyr_px * B / 1e6 + W * H * B / 1e6,
+                             "inside" if 2 * 1.05 * pyr_px * B + W * H * B < 256 * 2 ** 20 else "beyond"),
+                         "blur_plus_fast": {"full_work": {"achieved": both_full, "frac": both_full / HBM_PEAK_GBS},
+                                            "timed_region_bytes_touched": {"achieved": both_timed, "frac": both_timed / HBM_PEAK_GBS}},
+                         "kernels": kern,
+                         "pmc_counters": "profiles/r02/pmc_counters.json (same kernel sources)" if pmc else None},
             "roofline_kernels_ms": roof_ms,
-            "fast_tiles": {"full_work": fast_tiles[0], "total": fast_tiles[1],
-                           "early_exit_frac": 1.0 - fast_tiles[0] / max(fast_tiles[1], 1)},
+            "fast_tiles": {"full_work": fast_tiles[0], "total": fast_tiles[1], "early_exit_frac": 1.0 - work_frac},
             "stage_ms_per_step": stage_ms,
-            "fps_with_d2h": world * B / dt_d2h,
+            "stage_ms_per_step_fast_full_work": full_ms,
+            "fps_with_d2h": fps_d2h, "fps_with_d2h_blocking_fetch": fps_d2h_blocking,
             "fps_two_contexts_alternating": two_ctx_fps,
             "single_frame_host_to_host": single,
             "lk_track": lk,
             "match_consecutive": {"ms_per_batch": match_ms, "pairs": B - 1, "matches_pair0": n_matches,
                                   "what": "Hamming 2-NN + 0.8 ratio test, frame i -> i+1, device-resident"},
-            "keypoints_per_step": n_kp, "desc_checksum": csum,
+            "keypoints_batch0": n_kp, "desc_checksum": csum,
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames, pk) if args.workload == "kitti" else None
+        if stream_info:
+            out["stream"] = stream_info
+        if not args.no_cpu_baseline and args.workload == "kitti":
+            # the oracle on the very frames of batch 0: the bench checks itself (src/compare.cpp:39-62 is the
+            # reference's own, commented-out, CPU-vs-GPU descriptor check)
+            ref = oracle_results(frames0[:n0], pk)
+            want_cs = pkg.shard.descriptor_checksum([len(r["kps"]) for r in ref], [r["desc"] for r in ref])
+            kp_ok = all(int(res0["counts"][i]) == len(r["kps"]) and np.array_equal(res0["kps"][i, :len(r["kps"])], r["kps"])
+                        for i, r in enumerate(ref))
+            out["parity"] = {"checksum_match": bool(want_cs == cs0), "keypoints_match": bool(kp_ok),
+                             "frames_checked": len(ref), "oracle_keypoints": int(sum(len(r["kps"]) for r in ref)),
+                             "what": "every frame of batch 0 through oracle/liborb_oracle.so: keypoint lists equal, "
+                                     "descriptor checksum equal" + (" (rank 0's batch)" if world > 1 else "")}
+            out["cpu_baseline"] = cpu_baseline(frames0, pk)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
         print(json.dumps(out))
     ctx.close()
     if world > 1:

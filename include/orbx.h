@@ -123,7 +123,8 @@ int orbx_detect_and_compute(orbx_ctx* ctx, const uint8_t* image, int width, int 
  * context's device-side result slots until the next batched call. */
 int orbx_detect_and_compute_batch_device(orbx_ctx* ctx, const void* d_frames, int n, int width, int height,
                                          int row_stride, size_t frame_stride, void* stream);
-/* Same for `n` host frames (H2D copy included, pinned staging). */
+/* Same for `n` host frames (H2D copy from the caller's memory included; pass pinned memory for an
+ * asynchronous copy, pageable memory is staged by the HIP runtime). */
 int orbx_detect_and_compute_batch_host(orbx_ctx* ctx, const uint8_t* frames, int n, int width, int height,
                                        int row_stride, size_t frame_stride);
 /* Blocks until the last batched call has finished. */
@@ -149,6 +150,21 @@ int orbx_batch_results_device(orbx_ctx* ctx, orbx_batch_view* view);
 int orbx_batch_fetch(orbx_ctx* ctx, int first, int n, int32_t* counts, orbx_keypoint* keypoints,
                      float* orientations, orbx_descriptor* descriptors, float* responses, int32_t* levels,
                      orbx_keypoint* level_kps, int capacity);
+
+/* Pipelined consumers (a VO loop that wants the keypoints of frame batch i on the host while
+ * batch i+1 is being processed; the reference copies results back synchronously after every
+ * kernel, src/cuda/Fast.cu:238-239, src/cuda/Brief.cu:131).  The context keeps TWO result blocks
+ * and alternates between them:
+ *   orbx_detect_and_compute_batch_device(batch i);  orbx_batch_prefetch();
+ *   orbx_detect_and_compute_batch_device(batch i+1);          -- kernels overlap the copy of i
+ *   orbx_batch_fetch_previous(...)  -> results of batch i (waits for the copy only);  ...
+ * orbx_batch_prefetch starts an asynchronous D2H copy of the last batch's block into its pinned
+ * mirror on the context's copy stream; orbx_batch_fetch / _previous then wait for that copy
+ * instead of copying.  The results of batch i must be fetched before batch i+2 is submitted. */
+int orbx_batch_prefetch(orbx_ctx* ctx);
+int orbx_batch_fetch_previous(orbx_ctx* ctx, int first, int n, int32_t* counts, orbx_keypoint* keypoints,
+                              float* orientations, orbx_descriptor* descriptors, float* responses, int32_t* levels,
+                              orbx_keypoint* level_kps, int capacity);
 
 /* Per-stage device timings (ms) of the last batched call, in order:
  * pyramid, blur, fast+nms, compact, harris, select, orient+brief, total. */

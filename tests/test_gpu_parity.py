@@ -450,3 +450,36 @@ def test_graph_and_plain_launch_paths_agree(pkg, kitti0, kitti1):
         assert all(np.array_equal(a, b) for a, b in zip(got1, ref1))
         t = c.last_stage_times()
         assert t["total"] > 0
+
+
+def test_pipelined_result_fetch(pkg, kitti0, kitti1):
+    """Two result blocks: the D2H copy of batch i (orbx_batch_prefetch, copy stream) overlaps the kernels
+    of batch i+1; orbx_batch_fetch_previous then returns batch i.  Same results as the blocking fetch."""
+    import torch
+
+    batches = [np.stack([kitti0, kitti1]), np.stack([kitti1, np.roll(kitti0, (3, 7), (0, 1))]),
+               np.stack([kitti0[::-1].copy(), kitti1[:, ::-1].copy()]), np.stack([kitti1, kitti1])]
+    p = pkg.default_params("gpu", max_width=1241, max_height=376, max_batch=2, nfeatures=800, blur_levels=2)
+    keys = ("counts", "kps", "kps_level", "angles", "responses", "desc", "levels")
+    with pkg.Context(p) as c:
+        cap = c.plan(1241, 376)["out_capacity"]
+        dev = [torch.from_numpy(b).cuda() for b in batches]
+        torch.cuda.synchronize()
+        want = []
+        for d in dev:  # blocking reference
+            c.batch_device(d.data_ptr(), 2, 1241, 376)
+            want.append(c.batch_fetch(0, 2, cap))
+        for rounds in range(2):  # second round: the graph cache serves both result blocks
+            got = []
+            c.batch_device(dev[0].data_ptr(), 2, 1241, 376)
+            c.batch_prefetch()
+            for i in range(1, len(dev)):
+                c.batch_device(dev[i].data_ptr(), 2, 1241, 376)
+                got.append(c.batch_fetch(0, 2, cap, previous=True))
+                c.batch_prefetch()
+            got.append(c.batch_fetch(0, 2, cap))
+            for g, w in zip(got, want):
+                for k in keys:
+                    assert np.array_equal(g[k], w[k]), k
+        with pytest.raises(pkg.OrbxError):
+            pkg.Context(p).batch_fetch(0, 1, cap, previous=True)  # nothing has run yet

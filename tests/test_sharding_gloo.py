@@ -93,3 +93,34 @@ def test_split_helpers(pkg):
     a = s.descriptor_checksum(c, d)
     b = (s.descriptor_checksum(c[:1], d[:1]) + s.descriptor_checksum(c[1:], d[1:])) & 0x7FFFFFFFFFFFFFFF
     assert a == b and a != 0
+
+
+def _run_bench_stream(world, port, frames_per_eighth):
+    """bench.py --stream-frames with `world` gloo ranks, every rank on GPU 0 (the GPU worker, not the oracle)."""
+    import json
+
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--stream-frames",
+            str(frames_per_eighth), "--batch", "16", "--warmup", "1", "--no-cpu-baseline", "--only-timed",
+            "--dist-backend", "gloo", "--all-ranks-on-device0"]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(base, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    return json.loads(outs[0][0].strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+def test_two_gloo_ranks_with_the_gpu_worker_equal_one_rank(pkg):
+    """BASELINE.json configs[3] in small: a 96-frame stream walked by ONE rank and by TWO ranks (contiguous
+    blocks, shard.split_stream; both ranks on GPU 0, gloo for the reductions) gives the same keypoint
+    count and the same all-reduced descriptor checksum -- through liborbx.so, not the oracle."""
+    one = _run_bench_stream(1, 29641, 12)
+    two = _run_bench_stream(2, 29642, 12)
+    assert one["stream"]["total_frames"] == two["stream"]["total_frames"] == 96
+    assert two["n_gpus"] == 2 and two["stream"]["frames_this_rank"] == 48
+    assert one["stream"]["keypoints"] == two["stream"]["keypoints"] > 50000
+    assert one["stream"]["desc_checksum"] == two["stream"]["desc_checksum"]

@@ -62,10 +62,10 @@ OutLayout make_out_layout(int n, int cap) {
 struct OrbxGraphKey {
   const uint8_t* d_frames;
   size_t frame_stride;
-  int n, w, h, row_stride, early, plan_serial;
+  int n, w, h, row_stride, early, plan_serial, block;
   bool operator==(const OrbxGraphKey& o) const {
     return d_frames == o.d_frames && frame_stride == o.frame_stride && n == o.n && w == o.w && h == o.h &&
-           row_stride == o.row_stride && early == o.early && plan_serial == o.plan_serial;
+           row_stride == o.row_stride && early == o.early && plan_serial == o.plan_serial && block == o.block;
   }
 };
 
@@ -103,8 +103,8 @@ struct orbx_ctx {
   int32_t* d_cand_total = nullptr;
   float* d_resp = nullptr;
   // captured launch sequences of the most recent batch shapes (run_batch), round-robin replacement
-  static constexpr int kGraphs = 4;
-  hipGraphExec_t g_exec[kGraphs] = {nullptr, nullptr, nullptr, nullptr};
+  static constexpr int kGraphs = 8;
+  hipGraphExec_t g_exec[kGraphs] = {};
   OrbxGraphKey g_key[kGraphs] = {};
   int g_next = 0;
   int plan_serial = 0;  // bumped whenever set_plan rebuilds the plan / tables
@@ -114,6 +114,19 @@ struct orbx_ctx {
   OrbxResizeTap* d_taps = nullptr;
   size_t taps_capacity = 0;
   float* d_gauss = nullptr;
+  // Result blocks.  Two of them, used alternately by consecutive batches, each with a pinned host
+  // mirror: the D2H copy of batch i (orbx_batch_prefetch, on its own copy stream) overlaps the
+  // kernels of batch i+1, which write the other block.  d_out / h_out / out_layout / last_n always
+  // describe the block of the most recent batch.
+  uint8_t* d_outb[2] = {nullptr, nullptr};
+  uint8_t* h_outb[2] = {nullptr, nullptr};
+  OutLayout layoutb[2] = {};
+  int nb[2] = {0, 0};    // frames in the block (0: never written)
+  int capb[2] = {1, 1};  // slots per frame the block was written with
+  bool copy_pending[2] = {false, false};  // an asynchronous D2H of the block has been enqueued (ev_copied)
+  int blk = 0;
+  hipStream_t cstream = nullptr;
+  hipEvent_t ev_done[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
   uint8_t* d_out = nullptr;
   uint8_t* h_out = nullptr;  // pinned mirror
   OutLayout out_layout{};
@@ -652,13 +665,20 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   if (c->last_stream && c->last_stream != s) HIPCHK(c, hipStreamSynchronize(c->last_stream));
   int st = set_plan(c, w, h);
   if (st != ORBX_OK) return st;
+  // this batch writes the other result block; if that block is still the source of an
+  // asynchronous D2H copy (orbx_batch_prefetch two batches ago), the kernels wait for the copy
+  const int blk = c->blk ^ 1;
+  if (c->copy_pending[blk]) HIPCHK(c, hipStreamWaitEvent(s, c->ev_copied[blk], 0));
+  c->blk = blk;
+  c->d_out = c->d_outb[blk];
+  c->h_out = c->h_outb[blk];
   static const int use_graph = [] {
     const char* e = getenv("ORBX_GRAPH");
     return e ? atoi(e) : 1;
   }();
   const int tm = c->timing;
   if (use_graph && tm == 0) {
-    const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, fast_early_on(c) ? 1 : 0, c->plan_serial};
+    const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, fast_early_on(c) ? 1 : 0, c->plan_serial, blk};
     int gi = -1;
     for (int i = 0; i < orbx_ctx::kGraphs; i++)
       if (c->g_exec[i] && key == c->g_key[i]) gi = i;
@@ -688,6 +708,11 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   c->out_layout = make_out_layout(n, c->plan.out_cap > 0 ? c->plan.out_cap : 1);
   c->last_n = n;
   c->last_stream = s;
+  c->layoutb[blk] = c->out_layout;
+  c->nb[blk] = n;
+  c->capb[blk] = c->plan.out_cap > 0 ? c->plan.out_cap : 1;
+  c->copy_pending[blk] = false;
+  HIPCHK(c, hipEventRecord(c->ev_done[blk], s));
   if (tm != 0) {
     c->ev_mode[c->ev_calls % ORBX_EVENT_SETS] = tm;
     c->ev_calls++;
@@ -806,11 +831,20 @@ void orbx_destroy(orbx_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int i = 0; i < orbx_ctx::kGraphs; i++) drop_graph(c, i);
   void* bufs[] = {c->d_in,   c->d_pyr,  c->d_pyr_blur, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total,
-                  c->d_resp, c->d_taps, c->d_gauss,    c->d_out, c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur2, c->d_tiles_pyr2,
+                  c->d_resp, c->d_taps, c->d_gauss,    c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur2, c->d_tiles_pyr2,
                   c->d_lcand, c->d_lresp, c->d_lcount};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
-  if (c->h_out) (void)hipHostFree(c->h_out);
+  for (int i = 0; i < 2; i++) {
+    if (c->h_outb[i]) (void)hipHostFree(c->h_outb[i]);
+    if (c->d_outb[i]) (void)hipFree(c->d_outb[i]);
+    if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
+    if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
+  }
+  if (c->cstream) {
+    (void)hipStreamSynchronize(c->cstream);
+    (void)hipStreamDestroy(c->cstream);
+  }
   DevBuf* sb[] = {&c->s_img_a, &c->s_img_b, &c->s_f32,  &c->s_u16, &c->s_mask, &c->s_kps,   &c->s_f32b, &c->s_desc,
                   &c->s_i32,   &c->s_kern,  &c->s_tiles, &c->m_q,    &c->m_t,   &c->m_idx,  &c->m_dist,  &c->m_match, &c->m_cnt,
                   &c->lk_img[0], &c->lk_img[1], &c->lk_deriv, &c->lk_io};
@@ -925,8 +959,15 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
   c->out_cap = std::max(M.out_cap, 1);
   {
     const OutLayout o = make_out_layout((int)B, c->out_cap);
-    CREATE_CHK(hipMalloc((void**)&c->d_out, o.total));
-    CREATE_CHK(hipHostMalloc((void**)&c->h_out, o.total, hipHostMallocDefault));
+    CREATE_CHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+      CREATE_CHK(hipMalloc((void**)&c->d_outb[i], o.total));
+      CREATE_CHK(hipHostMalloc((void**)&c->h_outb[i], o.total, hipHostMallocDefault));
+      CREATE_CHK(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
+      CREATE_CHK(hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
+    }
+    c->d_out = c->d_outb[0];
+    c->h_out = c->h_outb[0];
   }
 #undef CREATE_CHK
   *out = c;
@@ -1062,22 +1103,26 @@ int orbx_batch_results_device(orbx_ctx* c, orbx_batch_view* v) {
   return ORBX_OK;
 }
 
-int orbx_batch_fetch(orbx_ctx* c, int first, int n, int32_t* counts, orbx_keypoint* keypoints,
-                     float* orientations, orbx_descriptor* descriptors, float* responses, int32_t* levels,
-                     orbx_keypoint* level_kps, int capacity) {
-  DeviceGuard _dg(c);
-  if (!c) return ORBX_ERR_INVALID_ARG;
+namespace {
+// frames [first, first+n) of result block `b` -> host arrays.  If an asynchronous copy of the block
+// is pending (orbx_batch_prefetch) only its event is waited for; otherwise ONE blocking D2H of the block.
+int fetch_block(orbx_ctx* c, int b, int first, int n, int32_t* counts, orbx_keypoint* keypoints, float* orientations,
+                orbx_descriptor* descriptors, float* responses, int32_t* levels, orbx_keypoint* level_kps,
+                int capacity) {
   if (!counts) return fail(c, ORBX_ERR_INVALID_ARG, "counts is NULL");
-  if (first < 0 || n < 1 || first + n > c->last_n) return fail(c, ORBX_ERR_INVALID_ARG, "frame range outside batch");
+  if (first < 0 || n < 1 || first + n > c->nb[b]) return fail(c, ORBX_ERR_INVALID_ARG, "frame range outside batch");
   if (capacity < 0) return fail(c, ORBX_ERR_INVALID_ARG, "capacity < 0");
-  const OutLayout& o = c->out_layout;
-  const int cap = c->plan.out_cap > 0 ? c->plan.out_cap : 1;
-  hipStream_t s = c->last_stream ? c->last_stream : c->stream;
-  // one D2H for the whole result block of the batch
-  HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, o.total, hipMemcpyDeviceToHost, s));
-  int st = orbx_wait(c);
-  if (st != ORBX_OK) return st;
-  const int32_t* hc = (const int32_t*)(c->h_out + o.counts);
+  const OutLayout& o = c->layoutb[b];
+  const int cap = c->capb[b];
+  const uint8_t* h = c->h_outb[b];
+  if (c->copy_pending[b]) {
+    HIPCHK(c, hipEventSynchronize(c->ev_copied[b]));
+  } else {
+    HIPCHK(c, hipStreamWaitEvent(c->cstream, c->ev_done[b], 0));
+    HIPCHK(c, hipMemcpyAsync(c->h_outb[b], c->d_outb[b], o.total, hipMemcpyDeviceToHost, c->cstream));
+    HIPCHK(c, hipStreamSynchronize(c->cstream));
+  }
+  const int32_t* hc = (const int32_t*)(h + o.counts);
   bool truncated = false;
   for (int i = 0; i < n; i++) {
     const int f = first + i;
@@ -1086,16 +1131,50 @@ int orbx_batch_fetch(orbx_ctx* c, int first, int n, int32_t* counts, orbx_keypoi
     const int m = std::min(cnt, capacity);
     if (cnt > capacity) truncated = true;
     const size_t so = (size_t)f * cap, dst = (size_t)i * capacity;
-    if (keypoints) std::memcpy(keypoints + dst, (const orbx_keypoint*)(c->h_out + o.kp) + so, sizeof(orbx_keypoint) * m);
-    if (level_kps) std::memcpy(level_kps + dst, (const orbx_keypoint*)(c->h_out + o.lkp) + so, sizeof(orbx_keypoint) * m);
-    if (orientations) std::memcpy(orientations + dst, (const float*)(c->h_out + o.angle) + so, sizeof(float) * m);
-    if (responses) std::memcpy(responses + dst, (const float*)(c->h_out + o.resp) + so, sizeof(float) * m);
-    if (levels) std::memcpy(levels + dst, (const int32_t*)(c->h_out + o.level) + so, sizeof(int32_t) * m);
+    if (keypoints) std::memcpy(keypoints + dst, (const orbx_keypoint*)(h + o.kp) + so, sizeof(orbx_keypoint) * m);
+    if (level_kps) std::memcpy(level_kps + dst, (const orbx_keypoint*)(h + o.lkp) + so, sizeof(orbx_keypoint) * m);
+    if (orientations) std::memcpy(orientations + dst, (const float*)(h + o.angle) + so, sizeof(float) * m);
+    if (responses) std::memcpy(responses + dst, (const float*)(h + o.resp) + so, sizeof(float) * m);
+    if (levels) std::memcpy(levels + dst, (const int32_t*)(h + o.level) + so, sizeof(int32_t) * m);
     if (descriptors)
-      std::memcpy(descriptors + dst, (const orbx_descriptor*)(c->h_out + o.desc) + so, sizeof(orbx_descriptor) * m);
+      std::memcpy(descriptors + dst, (const orbx_descriptor*)(h + o.desc) + so, sizeof(orbx_descriptor) * m);
   }
   if (truncated) return fail(c, ORBX_ERR_CAPACITY, "capacity smaller than keypoint count");
   return ORBX_OK;
+}
+}  // namespace
+
+int orbx_batch_fetch(orbx_ctx* c, int first, int n, int32_t* counts, orbx_keypoint* keypoints,
+                     float* orientations, orbx_descriptor* descriptors, float* responses, int32_t* levels,
+                     orbx_keypoint* level_kps, int capacity) {
+  DeviceGuard _dg(c);
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  return fetch_block(c, c->blk, first, n, counts, keypoints, orientations, descriptors, responses, levels, level_kps,
+                     capacity);
+}
+
+int orbx_batch_prefetch(orbx_ctx* c) {
+  DeviceGuard _dg(c);
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  const int b = c->blk;
+  if (c->nb[b] <= 0) return fail(c, ORBX_ERR_INVALID_ARG, "no batch has been run");
+  if (c->copy_pending[b]) return ORBX_OK;
+  HIPCHK(c, hipStreamWaitEvent(c->cstream, c->ev_done[b], 0));
+  HIPCHK(c, hipMemcpyAsync(c->h_outb[b], c->d_outb[b], c->layoutb[b].total, hipMemcpyDeviceToHost, c->cstream));
+  HIPCHK(c, hipEventRecord(c->ev_copied[b], c->cstream));
+  c->copy_pending[b] = true;
+  return ORBX_OK;
+}
+
+int orbx_batch_fetch_previous(orbx_ctx* c, int first, int n, int32_t* counts, orbx_keypoint* keypoints,
+                              float* orientations, orbx_descriptor* descriptors, float* responses, int32_t* levels,
+                              orbx_keypoint* level_kps, int capacity) {
+  DeviceGuard _dg(c);
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  const int b = c->blk ^ 1;
+  if (c->nb[b] <= 0) return fail(c, ORBX_ERR_INVALID_ARG, "there is no batch before the last one");
+  return fetch_block(c, b, first, n, counts, keypoints, orientations, descriptors, responses, levels, level_kps,
+                     capacity);
 }
 
 int orbx_detect_and_compute(orbx_ctx* c, const uint8_t* image, int width, int height, int stride,

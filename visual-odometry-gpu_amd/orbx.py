@@ -27,7 +27,8 @@ EXPORTS = [
     "orbx_params_default_gpu", "orbx_params_default_cpu", "orbx_create", "orbx_destroy",
     "orbx_last_error_string", "orbx_status_string", "orbx_version", "orbx_get_plan",
     "orbx_detect_and_compute", "orbx_detect_and_compute_batch_device", "orbx_detect_and_compute_batch_host",
-    "orbx_wait", "orbx_batch_results_device", "orbx_batch_fetch", "orbx_enable_stage_timing",
+    "orbx_wait", "orbx_batch_results_device", "orbx_batch_fetch", "orbx_batch_prefetch",
+    "orbx_batch_fetch_previous", "orbx_enable_stage_timing",
     "orbx_last_stage_times", "orbx_stage_times_history", "orbx_bench_stage", "orbx_set_fast_early_exit", "orbx_fast_tile_counts", "orbx_lk_track", "orbx_lk_pyramid_levels", "orbx_fast_score", "orbx_nms", "orbx_fast",
     "orbx_orientations", "orbx_brief", "orbx_harris", "orbx_blur5_sep", "orbx_blur5_273", "orbx_conv2d",
     "orbx_gaussian_blur_conv", "orbx_gaussian_kernel", "orbx_sobel", "orbx_build_pyramid_level",
@@ -237,7 +238,12 @@ class Context:
         self._chk(self._lib.orbx_batch_results_device(self._h, C.byref(v)))
         return v
 
-    def batch_fetch(self, first, n, capacity):
+    def batch_prefetch(self):
+        """Start the asynchronous D2H copy of the last batch's result block (overlaps the next batch)."""
+        self._chk(self._lib.orbx_batch_prefetch(self._h))
+
+    def batch_fetch(self, first, n, capacity, previous=False):
+        """Results of the last batch (previous=True: of the batch before it, see orbx_batch_fetch_previous)."""
         counts = np.zeros(n, np.int32)
         kps = np.zeros((n, capacity, 2), np.int32)
         lkp = np.zeros((n, capacity, 2), np.int32)
@@ -245,8 +251,9 @@ class Context:
         resp = np.zeros((n, capacity), np.float32)
         lev = np.zeros((n, capacity), np.int32)
         desc = np.zeros((n, capacity, 32), np.uint8)
-        st = self._lib.orbx_batch_fetch(self._h, first, n, _ptr(counts), _ptr(kps), _ptr(ang), _ptr(desc), _ptr(resp),
-                                        _ptr(lev), _ptr(lkp), capacity)
+        fn = self._lib.orbx_batch_fetch_previous if previous else self._lib.orbx_batch_fetch
+        st = fn(self._h, first, n, _ptr(counts), _ptr(kps), _ptr(ang), _ptr(desc), _ptr(resp), _ptr(lev), _ptr(lkp),
+                capacity)
         self._chk(st, allow=(ERR_CAPACITY,))
         return dict(counts=counts, kps=kps, kps_level=lkp, angles=ang, responses=resp, levels=lev, desc=desc,
                     status=st)
