@@ -185,6 +185,12 @@ int orbx_stage_times_history(orbx_ctx* ctx, int back, float* ms);
  * to measure the kernel's full-work throughput).  Default: enabled. */
 int orbx_set_fast_early_exit(orbx_ctx* ctx, int enable);
 
+/* With blur on every level (ORBX_BLUR_ALL, separable kind) the batched path builds and blurs the
+ * pyramid in ONE kernel (buildPyramid + GaussianBlur of src/orb_cpu.cpp:278-290 fused: the
+ * un-blurred pyramid is never written).  enable = 0 runs the two kernels separately (identical
+ * results; used to time / profile each kernel on its own).  Default: enabled. */
+int orbx_set_fused_pyramid_blur(orbx_ctx* ctx, int enable);
+
 /* Diagnostics of the last whole-path batch: how many FAST/NMS tiles did the full
  * work (`worked`) out of all tiles of the batch (`total`); the rest took the early
  * exit.  With the early exit disabled worked == total. */

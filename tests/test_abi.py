@@ -109,6 +109,6 @@ def test_no_result_altering_environment_switch_in_the_shipping_library():
         "ORBX_GRAPH",          # 0: plain launches instead of the captured hipGraph
         "ORBX_SELECT_SPREAD",  # fused vs three-kernel selection
         "ORBX_BLUR_IMPL",      # first- vs second-generation separable blur kernel
-        "ORBX_BLUR2_RH",       # rows per wave of the streaming blur
+        "ORBX_FUSE",           # 0: pyramid and blur as two kernels instead of one
     }
     assert found <= allowed, sorted(found - allowed)

@@ -483,3 +483,29 @@ def test_pipelined_result_fetch(pkg, kitti0, kitti1):
                     assert np.array_equal(g[k], w[k]), k
         with pytest.raises(pkg.OrbxError):
             pkg.Context(p).batch_fetch(0, 1, cap, previous=True)  # nothing has run yet
+
+
+@pytest.mark.parametrize("shape", [(376, 1241), (120, 160), (64, 250), (65, 497), (200, 70), (33, 257), (90, 745)])
+def test_fused_pyramid_blur_equals_separate_kernels(pkg, shape):
+    """Blur on every level: the batched path builds and blurs the pyramid in one kernel (k_pyrblur); with
+    orbx_set_fused_pyramid_blur(0) the two kernels run separately.  Same results, equal to the oracle
+    (strip / lane / band boundaries of both kernels, both resize gather modes: 8 levels reach scale 3.6)."""
+    h, w = shape
+    img = synth(h * 7 + w, h, w, "noise" if min(h, w) < 100 else "rects")
+    nl = 8 if min(h, w) >= 60 else 4
+    kw = dict(nfeatures=600, nlevels=nl, blur_levels=2)
+    p = pkg.default_params("gpu", max_width=w, max_height=h, max_batch=3, **kw)
+    frames = np.stack([img, img[::-1].copy(), np.roll(img, 5, 1)])
+    with pkg.Context(p) as c:
+        cap = max(c.plan(w, h)["out_capacity"], 1)
+        c.batch_host(frames)
+        a = c.batch_fetch(0, 3, cap)
+        c.set_fused_pyramid_blur(False)
+        c.batch_host(frames)
+        b = c.batch_fetch(0, 3, cap)
+        for k in ("counts", "kps", "kps_level", "angles", "desc", "levels", "responses"):
+            assert np.array_equal(a[k], b[k]), k
+    ref = O.detect_and_compute_gpu(frames[1], O.gpu_params(**kw))
+    n = int(a["counts"][1])
+    assert n == len(ref["kps"]) and np.array_equal(a["kps"][1, :n], ref["kps"])
+    assert np.array_equal(a["desc"][1, :n], ref["desc"])

@@ -87,6 +87,8 @@ struct orbx_ctx {
   int fast_tiles_count = 0;
   OrbxTileDesc* d_tiles_blur2 = nullptr;
   OrbxTileDesc* d_tiles_pyr2 = nullptr;
+  OrbxTileDesc* d_tiles_pyrblur = nullptr;  // fused pyramid + blur strips
+  int pyrblur_tiles_count = 0;
   size_t tiles_frame_capacity = 0;
   int blur2_tiles_count = 0, pyr2_tiles_count = 0;
   DevBuf s_tiles;  // stage-API tables
@@ -147,6 +149,7 @@ struct orbx_ctx {
 
   int timing = 0;  // 0 off, 1 all stages, 2 blur + fast only
   int fast_early = 1;
+  int fuse = 1;  // pyramid + blur in one kernel when blur runs on every level (orbx_set_fused_pyramid_blur)
   // ring of event sets: one per timed batched call, so that several calls can be
   // in flight before their stage times are read (no host sync between steps)
   hipEvent_t evr[ORBX_EVENT_SETS][ORBX_NUM_STAGE_TIMES + 1] = {};
@@ -360,6 +363,33 @@ void build_blur_tiles(const OrbxPlan& plan, std::vector<OrbxTileDesc>* out) {
   }
 }
 
+// strips of the fused pyramid + blur kernel for ONE frame: 248-px strips (the halo dwords are
+// computed by lanes 0 / 63) x balanced row bands, with the level's resize-table fields
+void build_pyrblur_tiles(const OrbxPlan& plan, std::vector<OrbxTileDesc>* out) {
+  out->clear();
+  for (int l = 0; l < plan.nlevels; l++) {
+    const OrbxLevel& L = plan.L[l];
+    const int ntx = (L.pitch + ORBX_PYRBLUR_TW - 1) / ORBX_PYRBLUR_TW;  // the padding bytes are (re)written as zeros
+    const int nb = (L.h + ORBX_BLUR3_RH - 1) / ORBX_BLUR3_RH, rows = (L.h + nb - 1) / nb;
+    for (int b = 0; b < nb; b++)
+      for (int tx = 0; tx < ntx; tx++) {
+        OrbxTileDesc d{};
+        d.l = l;
+        d.tx = tx;
+        d.ty = b * rows;
+        d.f = std::min(rows, L.h - b * rows);
+        d.w = L.w;
+        d.h = L.h;
+        d.pitch = L.pitch;
+        d.u0 = L.xtab_off;
+        d.u1 = L.ytab_off;
+        d.u2 = L.win8;
+        d.img_off = (uint64_t)L.img_off;
+        if (d.f > 0) out->push_back(d);
+      }
+  }
+}
+
 int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string* why) {
   std::memset(plan, 0, sizeof(*plan));
   plan->nlevels = p.nlevels;
@@ -535,6 +565,10 @@ int set_plan(orbx_ctx* c, int w, int h) {
     if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "blur tile table exceeds pool");
     HIPCHK(c, hipMemcpy(c->d_tiles_blur2, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
     c->blur2_tiles_count = (int)t.size();
+    build_pyrblur_tiles(plan, &t);
+    if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "strip table exceeds pool");
+    HIPCHK(c, hipMemcpy(c->d_tiles_pyrblur, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
+    c->pyrblur_tiles_count = (int)t.size();
     build_frame_tiles(plan, ORBX_PYR2_TW, ORBX_PYR2_TH, true, &t);
     if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "pyramid tile table exceeds pool");
     HIPCHK(c, hipMemcpy(c->d_tiles_pyr2, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
@@ -562,6 +596,14 @@ hipError_t launch_pyramid_auto(orbx_ctx* c, hipStream_t s, int n, const uint8_t*
 
 
 bool blur_enabled(const orbx_ctx* c) { return c->p.blur_levels != ORBX_BLUR_NONE; }
+// ORBX_FUSE=0: separate pyramid and blur kernels (same results; A/B timing and per-kernel profiles)
+bool fused_pyrblur(const orbx_ctx* c) {
+  static const int env = [] {
+    const char* e = getenv("ORBX_FUSE");
+    return e ? atoi(e) : 1;
+  }();
+  return env && c->fuse && c->p.blur_levels == ORBX_BLUR_ALL && c->p.blur_kind == ORBX_BLUR_SEP16;
+}
 const uint8_t* final_pyr(const orbx_ctx* c);
 
 // FAST + NMS of the batched path.  Tiles that provably cannot contribute to the
@@ -616,11 +658,19 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
   // around the FAST stage bracket the kernel alone
   HIPCHK(c, hipMemsetAsync(c->d_row_stat, 0, (size_t)n * ORBX_FAST_STAT_WORDS * 8, s));
   HIPCHK(c, mark(0, false));
-  HIPCHK(c, launch_pyramid_auto(c, s, n, d_frames, row_stride, frame_stride));
-  HIPCHK(c, mark(1, true));
-  if (blur_enabled(c))
-    HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->d_tiles_blur2, c->blur2_tiles_count, n, c->d_pyr, c->d_pyr_blur,
-                               c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
+  if (fused_pyrblur(c)) {
+    // blur on every level: pyramid and blur in one pass, the un-blurred pyramid is never materialised
+    // (the event slots then read: pyramid = 0, blur = the fused kernel)
+    HIPCHK(c, mark(1, true));
+    HIPCHK(c, orbx_launch_pyrblur(s, c->d_tiles_pyrblur, c->pyrblur_tiles_count, P.frame_bytes, P.w0, P.h0, n,
+                                  d_frames, row_stride, frame_stride, c->d_taps, c->d_pyr_blur));
+  } else {
+    HIPCHK(c, launch_pyramid_auto(c, s, n, d_frames, row_stride, frame_stride));
+    HIPCHK(c, mark(1, true));
+    if (blur_enabled(c))
+      HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->d_tiles_blur2, c->blur2_tiles_count, n, c->d_pyr,
+                                 c->d_pyr_blur, c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
+  }
   HIPCHK(c, mark(2, true));
   OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2};
   HIPCHK(c, launch_fast_whole(c, s, n, fp, true));
@@ -678,7 +728,8 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   }();
   const int tm = c->timing;
   if (use_graph && tm == 0) {
-    const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, fast_early_on(c) ? 1 : 0, c->plan_serial, blk};
+    const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, (fast_early_on(c) ? 1 : 0) | (fused_pyrblur(c) ? 2 : 0),
+                           c->plan_serial, blk};
     int gi = -1;
     for (int i = 0; i < orbx_ctx::kGraphs; i++)
       if (c->g_exec[i] && key == c->g_key[i]) gi = i;
@@ -831,7 +882,7 @@ void orbx_destroy(orbx_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int i = 0; i < orbx_ctx::kGraphs; i++) drop_graph(c, i);
   void* bufs[] = {c->d_in,   c->d_pyr,  c->d_pyr_blur, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total,
-                  c->d_resp, c->d_taps, c->d_gauss,    c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur2, c->d_tiles_pyr2,
+                  c->d_resp, c->d_taps, c->d_gauss,    c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur2, c->d_tiles_pyr2, c->d_tiles_pyrblur,
                   c->d_lcand, c->d_lresp, c->d_lcount};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -931,7 +982,10 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
     std::vector<OrbxTileDesc> t1, t2;
     build_blur_tiles(M, &t1);
     build_frame_tiles(M, ORBX_PYR2_TW, ORBX_PYR2_TH, true, &t2);
-    c->tiles_frame_capacity = std::max(t1.size(), t2.size()) + 64;
+    std::vector<OrbxTileDesc> t3;
+    build_pyrblur_tiles(M, &t3);
+    c->tiles_frame_capacity = std::max(std::max(t1.size(), t2.size()), t3.size()) + 64;
+    CREATE_CHK(hipMalloc((void**)&c->d_tiles_pyrblur, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_blur2, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_pyr2, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
   }
@@ -1037,6 +1091,13 @@ int orbx_set_fast_early_exit(orbx_ctx* c, int enable) {
   DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   c->fast_early = enable != 0;
+  return ORBX_OK;
+}
+
+int orbx_set_fused_pyramid_blur(orbx_ctx* c, int enable) {
+  DeviceGuard _dg(c);
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  c->fuse = enable != 0;
   return ORBX_OK;
 }
 

@@ -201,6 +201,239 @@ __global__ __launch_bounds__(256) void k_blur3(const OrbxTileDesc* __restrict__ 
     blur3_strip<false>(S);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pyramid + blur in ONE pass (whole path, blur on every level): the wave produces each row of its
+// strip of level l straight from the input frame -- level 0: the frame's own pixels; level >= 1:
+// OpenCV's 8UC1 fixed-point bilinear resize of level 0 (src/orb.cpp:111-120; the arithmetic of
+// k_pyramid2, orbx_kernels.hip) -- and feeds it to the streaming blur above.  The un-blurred
+// pyramid is never written nor read back: 2 x 1.5 MB of traffic per frame and one launch less.
+// The halo dwords of a strip have to be COMPUTED here, not loaded, so this kernel keeps the
+// 248-pixel strips (lanes 1..62 productive, lanes 0 / 63 compute the halo and store nothing).
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
+struct __attribute__((packed, aligned(1))) uint2_unaligned {
+  uint32_t x, y;
+};
+
+struct PyrSrc {
+  const uint8_t* src;  // level 0 = the input frame
+  int in_stride, w0, h0;
+  const OrbxResizeTap* ytaps;  // y taps of this level
+  int x, w, h;                 // lane x, level size
+};
+struct PyrLane {  // x taps of the lane's four pixels
+  uint32_t ofs[4], cc[4], sel[4], base;
+};
+
+// MODE 0: level 0 (one unaligned dword of the frame); 1: resize through one 8-byte window per source
+// row (scale <= 2, host-verified per level); 2: resize with four 2-byte pair gathers per source row
+template <int MODE>
+struct PyrRaw {
+  uint32_t q0[MODE == 0 ? 1 : MODE == 1 ? 2 : 4], q1[MODE == 0 ? 1 : MODE == 1 ? 2 : 4];
+  int b0, b1;
+};
+
+// issue the loads of output row yl (already reflected into [0, h))
+template <int MODE>
+__device__ __forceinline__ void pyr_issue(const PyrSrc& P, const PyrLane& T, int yl, PyrRaw<MODE>& R) {
+  if (MODE == 0) {
+    const uint8_t* row = P.src + (size_t)yl * P.in_stride;
+    const int nvalid = P.w - P.x;
+    uint32_t v = 0;
+    if (P.x >= 0 && (nvalid >= 4 || (nvalid > 0 && yl + 1 < P.h))) {
+      // (a partial last dword of a row above the last one runs into the next row of the same
+      // frame: readable, the blur's column patch / byte mask ignores those bytes)
+      v = *reinterpret_cast<const u32_unaligned*>(row + P.x);
+    } else if (P.x >= 0 && nvalid > 0) {  // last dword of the last row: never read past the frame
+      for (int k = 0; k < nvalid; k++) v |= (uint32_t)row[P.x + k] << (8 * k);
+    }
+    R.q0[0] = v;
+    R.b0 = R.b1 = 0;
+    return;
+  }
+  const OrbxResizeTap ty = P.ytaps[yl];  // wave-uniform -> scalar load
+  const int sy0 = min(max(ty.ofs, 0), P.h0 - 1), sy1 = min(max(ty.ofs + 1, 0), P.h0 - 1);
+  const uint8_t* S0 = P.src + (size_t)sy0 * P.in_stride;
+  const uint8_t* S1 = P.src + (size_t)sy1 * P.in_stride;
+  R.b0 = ty.c0;
+  R.b1 = ty.c1;
+  if (MODE == 1) {
+    const uint2_unaligned a = *reinterpret_cast<const uint2_unaligned*>(S0 + T.base);
+    const uint2_unaligned b = *reinterpret_cast<const uint2_unaligned*>(S1 + T.base);
+    R.q0[0] = a.x;
+    R.q0[1] = a.y;
+    R.q1[0] = b.x;
+    R.q1[1] = b.y;
+  } else {
+#pragma unroll
+    for (int k = 0; k < (MODE == 2 ? 4 : 0); k++) {
+      // ofs <= w0-2 always (host table): one unaligned 16-bit load fetches src[ofs], src[ofs+1]
+      R.q0[k] = *reinterpret_cast<const u16_unaligned*>(S0 + T.ofs[k]);
+      R.q1[k] = *reinterpret_cast<const u16_unaligned*>(S1 + T.ofs[k]);
+    }
+  }
+}
+
+// the row's dword of four level pixels (OpenCV: ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2)
+template <int MODE>
+__device__ __forceinline__ uint32_t pyr_finish(const PyrLane& T, const PyrRaw<MODE>& R) {
+  if (MODE == 0) return R.q0[0];
+  uint32_t out = 0;
+  const uint32_t bs0 = ((uint32_t)R.b0 << 12) & 0xffffffu, bs1 = ((uint32_t)R.b1 << 12) & 0xffffffu;  // b <= 2048
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint32_t p0, p1;  // the pixel pair as two u16 lanes
+    if (MODE == 1) {
+      p0 = __builtin_amdgcn_perm(R.q0[1], R.q0[0], T.sel[k]);
+      p1 = __builtin_amdgcn_perm(R.q1[1], R.q1[0], T.sel[k]);
+    } else {
+      p0 = __builtin_amdgcn_perm(R.q0[MODE == 2 ? k : 0], R.q0[MODE == 2 ? k : 0], 0x0c010c00u);
+      p1 = __builtin_amdgcn_perm(R.q1[MODE == 2 ? k : 0], R.q1[MODE == 2 ? k : 0], 0x0c010c00u);
+    }
+    // horizontal pass: src[ofs] * c0 + src[ofs+1] * c1 is one v_dot2_u32_u16 of the pixel pair
+    // with the tap's packed (c0, c1)
+    const us2_t cw = __builtin_bit_cast(us2_t, T.cc[k]);
+    const uint32_t r0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, p0), cw, 0u, false);
+    const uint32_t r1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, p1), cw, 0u, false);
+    // vertical pass: (b * (r >> 4)) >> 16 == ((r & ~15) * (b << 12)) >> 32 with both factors below
+    // 2^24: one v_and + one full-rate v_mul_hi_u32_u24 per term; the sum is <= 1022
+    const uint32_t t0 = (uint32_t)(((u64)(r0 & 0xfffff0u) * (u64)bs0) >> 32);
+    const uint32_t t1 = (uint32_t)(((u64)(r1 & 0xfffff0u) * (u64)bs1) >> 32);
+    out |= ((t0 + t1 + 2u) >> 2) << (8 * k);
+  }
+  return out;
+}
+
+template <int MODE, bool PATCH>
+__device__ __forceinline__ void pyrblur_strip(const Blur3Strip& S, const PyrSrc& P, const PyrLane& T) {
+  // Loads in flight per wave: the five rows of a group (modes 0 and 1: <= 4 registers per row), or the
+  // next row only (pair-gather mode: 8 registers per row).  With <= 64 registers the kernel keeps 8
+  // waves per SIMD, i.e. ALL waves of a 64-frame KITTI batch are resident at once (7.4 per SIMD): at
+  // 6 per SIMD the second, partly filled round of waves cost 40 % (100 us instead of 70).
+  constexpr int NB = MODE == 2 ? 2 : 5;
+  const uint32_t k4 = pk_opaque(0x00040004u), k6 = pk_opaque(0x00060006u);
+  uint32_t he[5], ho[5];
+  PyrRaw<MODE> raw[NB];
+  // input row r of the strip is level row y0 - 2 + r; output row y0 + r - 4 is complete after row r
+  const int nr = S.yend - S.y0 + 4;  // input rows
+  // (rows past the strip, in the last group, are computed from clamped indices and never stored)
+  auto issue = [&](int r, PyrRaw<MODE>& R) { pyr_issue<MODE>(P, T, reflect101_s(S.y0 - 2 + min(r, nr + 1), S.h), R); };
+  auto hpass = [&](int rb, int k) {
+    if (MODE == 2 && k < 4) issue(rb + k + 1, raw[(k + 1) & 1]);
+    blur3_h<PATCH>(S, pyr_finish<MODE>(T, raw[MODE == 2 ? (k & 1) : k]), 0u, k4, k6, he[k], ho[k]);
+  };
+  auto fetch_group = [&](int rb) {
+    if (MODE == 2) {
+      issue(rb, raw[0]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 5; k++) issue(rb + k, raw[MODE == 2 ? 0 : k]);
+    }
+  };
+  fetch_group(0);
+#pragma unroll
+  for (int k = 0; k < 5; k++) hpass(0, k);
+  blur3_v<PATCH>(S, he, ho, 0, 1, 2, 3, 4, k4, k6, S.y0);
+  for (int rb = 5; rb < nr; rb += 5) {  // wave-uniform
+    fetch_group(rb);
+    const int y = S.y0 + rb - 4;
+    hpass(rb, 0);
+    blur3_v<PATCH>(S, he, ho, 1, 2, 3, 4, 0, k4, k6, y);
+    hpass(rb, 1);
+    blur3_v<PATCH>(S, he, ho, 2, 3, 4, 0, 1, k4, k6, y + 1);
+    hpass(rb, 2);
+    blur3_v<PATCH>(S, he, ho, 3, 4, 0, 1, 2, k4, k6, y + 2);
+    hpass(rb, 3);
+    blur3_v<PATCH>(S, he, ho, 4, 0, 1, 2, 3, k4, k6, y + 3);
+    hpass(rb, 4);
+    blur3_v<PATCH>(S, he, ho, 0, 1, 2, 3, 4, k4, k6, y + 4);
+  }
+}
+
+// grid = (strip table entries of ONE frame / 4, frames); entry: level `l`, strip `tx` (248 px), rows
+// [ty, ty + f), u0 / u1 / u2 = x-tap offset / y-tap offset / 8-byte-window flag of the level.
+__global__ __launch_bounds__(256, 8) void k_pyrblur(const OrbxTileDesc* __restrict__ tiles, int n_tiles, int frame_bytes,
+                                                 int w0, int h0, const uint8_t* __restrict__ in, int in_stride,
+                                                 size_t in_frame_stride, const OrbxResizeTap* __restrict__ taps,
+                                                 uint8_t* __restrict__ dst) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ti = blockIdx.x * 4 + wave;
+  if (ti >= n_tiles) return;  // whole wave
+  const OrbxTileDesc d = tiles[ti];
+  const int w = d.w, h = d.h, pitch = d.pitch;
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int x = d.tx * ORBX_PYRBLUR_TW - 4 + lane * 4;  // lane 0 holds the dword left of the strip
+  Blur3Strip S;
+  S.y0 = d.ty;
+  S.yend = min(d.ty + d.f, h);
+  S.h = h;
+  S.pitch = pitch;
+  if (S.y0 >= S.yend) return;
+  S.rin = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0, 0x00020000);  // (unused: rows are computed, not loaded)
+  S.rout = __builtin_amdgcn_make_buffer_rsrc(dst + ((size_t)f * frame_bytes + d.img_off), 0, pitch * h, 0x00020000);
+  S.voff = (lane >= 1 && lane <= 62 && x < pitch) ? (uint32_t)x : 0xffffffffu;
+  S.voff_halo = 0xffffffffu;
+  // column REFLECT_101 selectors, as in k_blur3
+  const int e4 = (w - 1) & ~3, rbyte = (w - 1) & 3;
+  const bool edge = (x == e4);
+  S.selL = x == 0 ? 0x05060c0cu : 0x03020100u;
+  const uint32_t selC_e = rbyte == 3 ? 0x07060504u : rbyte == 2 ? 0x05060504u : rbyte == 1 ? 0x03040504u : 0x07020304u;
+  S.selC = edge ? selC_e : 0x07060504u;
+  const uint32_t selR_e = rbyte == 3 ? 0x0c0c0506u : rbyte == 2 ? 0x0c0c0c04u : 0x0c0c0c0cu;
+  S.selR = edge ? selR_e : 0x03020100u;
+  const int nvalid = w - x;
+  S.vmask = nvalid >= 4 ? 0xffffffffu : nvalid <= 0 ? 0u : ((1u << (8 * nvalid)) - 1u);
+  const int x_lo = d.tx * ORBX_PYRBLUR_TW - 4, x_hi = x_lo + 4 * 63;
+  const bool patch = (x_lo <= 0) || (e4 >= x_lo && e4 <= x_hi);  // wave-uniform
+
+  PyrSrc P;
+  P.src = in + (size_t)f * in_frame_stride;
+  P.in_stride = in_stride;
+  P.w0 = w0;
+  P.h0 = h0;
+  P.ytaps = taps + d.u1;
+  P.x = x;
+  P.w = w;
+  P.h = h;
+  PyrLane T;
+#pragma unroll
+  for (int k = 0; k < 4; k++) T.ofs[k] = T.cc[k] = T.sel[k] = 0;
+  T.base = 0;
+  if (d.l == 0) {
+    if (patch)
+      pyrblur_strip<0, true>(S, P, T);
+    else
+      pyrblur_strip<0, false>(S, P, T);
+    return;
+  }
+  // x taps of this lane's four pixels (zero taps for lanes outside the image)
+  if (x >= 0 && x < w) {
+    const uint4* tp = reinterpret_cast<const uint4*>(taps + d.u0 + x);
+    const uint4 t01 = tp[0], t23 = tp[1];
+    T.ofs[0] = t01.x; T.ofs[1] = t01.z; T.ofs[2] = t23.x; T.ofs[3] = t23.z;
+    T.cc[0] = t01.y; T.cc[1] = t01.w; T.cc[2] = t23.y; T.cc[3] = t23.w;
+  }
+  if (d.u2) {
+    // the window start is clamped so that it never reads past the source row
+    T.base = min(T.ofs[0], (uint32_t)(w0 - 8));
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t sb = T.ofs[k] - T.base;             // 0..6
+      T.sel[k] = 0x0c000c00u | ((sb + 1) << 16) | sb;    // (src[ofs], src[ofs+1]) as two u16 lanes
+    }
+    if (patch)
+      pyrblur_strip<1, true>(S, P, T);
+    else
+      pyrblur_strip<1, false>(S, P, T);
+  } else {
+    if (patch)
+      pyrblur_strip<2, true>(S, P, T);
+    else
+      pyrblur_strip<2, false>(S, P, T);
+  }
+}
+
 }  // namespace
 
 // separable blur of every level >= first_level (lower levels are copied); d_tiles: the strip table
@@ -211,5 +444,17 @@ hipError_t orbx_launch_blur3(hipStream_t s, const OrbxTileDesc* d_tiles, int n_t
   // four waves per workgroup (measured: 1 -> 53 us, 2 -> 48 us, 4 -> 43 us, 8 / 16 -> 46 us per 64-frame batch)
   dim3 grid((n_tiles + 3) / 4, n_frames);
   hipLaunchKernelGGL(k_blur3, grid, dim3(256), 0, s, d_tiles, n_tiles, frame_bytes, d_src, d_dst, first_level);
+  return hipGetLastError();
+}
+
+// pyramid + blur of every level in one pass (blur on every level, separable kind); d_tiles: the strip
+// table of ONE frame (orbx_api.cpp: build_pyrblur_tiles)
+hipError_t orbx_launch_pyrblur(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int w0, int h0,
+                               int n_frames, const uint8_t* d_in, int in_stride, size_t in_frame_stride,
+                               const OrbxResizeTap* d_taps, uint8_t* d_dst) {
+  if (n_tiles <= 0 || n_frames <= 0) return hipSuccess;
+  dim3 grid((n_tiles + 3) / 4, n_frames);
+  hipLaunchKernelGGL(k_pyrblur, grid, dim3(256), 0, s, d_tiles, n_tiles, frame_bytes, w0, h0, d_in, in_stride,
+                     in_frame_stride, d_taps, d_dst);
   return hipGetLastError();
 }

@@ -110,6 +110,8 @@ constexpr int orbx_fast3_tile_h(int nms_radius) {
 // 256-byte segment per row) over a band of at most ORBX_BLUR3_RH rows
 #define ORBX_BLUR3_TW 256
 #define ORBX_BLUR3_RH 64
+// fused pyramid + blur: the halo dwords are computed, not loaded, so lanes 0 / 63 are halo-only
+#define ORBX_PYRBLUR_TW 248
 // pyramid kernel: a wave owns 256 x 8 pixels (level 0 and the levels resized through 8-byte
 // windows) or 256 x 4, a workgroup four times that; OrbxTileDesc::f carries the rows per wave
 #define ORBX_PYR2_TW 256
@@ -147,6 +149,10 @@ hipError_t orbx_launch_blur(hipStream_t s, const OrbxPlan& plan, const OrbxTileM
 // d_tiles: strip table of ONE frame (level, strip, first row, rows)
 hipError_t orbx_launch_blur3(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int n_frames,
                              const uint8_t* d_src, uint8_t* d_dst, int first_level);
+// d_tiles: strip table of ONE frame with the pyramid fields (u0 / u1 / u2 = xtab_off / ytab_off / win8)
+hipError_t orbx_launch_pyrblur(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int w0, int h0,
+                               int n_frames, const uint8_t* d_in, int in_stride, size_t in_frame_stride,
+                               const OrbxResizeTap* d_taps, uint8_t* d_dst);
 // d_tiles: n_tiles OrbxTileDesc in band-major order (orbx_api.cpp: build_fast_tiles, tile height
 // orbx_fast3_tile_h(fp.nms_radius)); d_scores: optional dense u16 score map of ONE frame (stage operator)
 hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int n_frames,
