@@ -212,6 +212,8 @@ def main():
                          "per-kernel averages must describe the timed configuration only")
     ap.add_argument("--full-work", action="store_true",
                     help="run the TIMED region with the FAST early exit off (for rocprofv3 runs of the full-work kernel)")
+    ap.add_argument("--unfused", action="store_true",
+                    help="run the TIMED region with separate pyramid and blur kernels (for rocprofv3 runs of each kernel)")
     ap.add_argument("--pmc-file", default=PMC_FILE,
                     help="per-kernel counters from separate rocprofv3 --pmc passes of THIS build (tools/pmc_collect.sh)")
     args = ap.parse_args()
@@ -296,6 +298,8 @@ def main():
 
     if args.full_work:
         ctx.set_fast_early_exit(False)
+    if args.unfused:
+        ctx.set_fused_pyramid_blur(False)
     for i in range(args.warmup):
         submit(i)
         ctx.wait()
@@ -365,6 +369,14 @@ def main():
         ctx.set_fast_early_exit(True)
     if args.full_work:
         full_ms = dict(stage_ms) if not args.only_timed else dict(zero, fast_nms=roof_ms["fast_nms"], blur=roof_ms["blur"])
+    # the pyramid and blur kernels on their own (the timed region runs them fused into one kernel)
+    unfused_ms = None
+    if not args.only_timed and not args.unfused:
+        ctx.set_fused_pyramid_blur(False)
+        submit(0)
+        ctx.wait()
+        unfused_ms = breakdown()
+        ctx.set_fused_pyramid_blur(True)
     ctx.enable_stage_timing(0)
 
     # ---- results of batch 0 (for the checksum and the oracle comparison)
@@ -479,9 +491,22 @@ def main():
             return e
 
         work_frac = fast_tiles[0] / max(fast_tiles[1], 1)
-        kern = {
-            "pyramid": entry("pyramid", alg["pyramid"], stage_ms["pyramid"], "k_pyramid2"),
-            "blur": entry("blur", alg["blur"], roof_ms["blur"], "k_blur3"),
+        fused = not args.unfused
+        kern = {}
+        if fused:
+            # the timed region builds and blurs the pyramid in ONE kernel.  Charged with the stage figures of
+            # SURVEY.md §8d (resize + blur); `bytes_moved` = what the fused kernel has to move at all (level 0
+            # read once + every blurred level written once)
+            moved = (W * H + pyr_px) * B
+            kern["pyramid_blur_fused_timed_region"] = entry(
+                "pyrblur", (W * H + (pyr_px - W * H)) * B + alg["blur"], roof_ms["blur"], "k_pyrblur",
+                {"compulsory_bytes_of_the_fused_kernel": moved, "achieved_GBps_compulsory": gbs(moved, roof_ms["blur"]),
+                 "note": "charged with SURVEY.md §8d's resize + blur figures; the un-blurred pyramid is never written"})
+        src_ms = unfused_ms if fused else stage_ms
+        if src_ms:
+            kern["pyramid_alone"] = entry("pyramid", alg["pyramid"], src_ms["pyramid"], "k_pyramid2")
+            kern["blur_alone"] = entry("blur", alg["blur"], src_ms["blur"] if fused else roof_ms["blur"], "k_blur3")
+        kern.update({
             "fast_nms_full_work": entry("fast_nms", alg["fast_nms"], full_ms["fast_nms"], "k_fast3_full_work",
                                         {"tiles_worked": full_tiles[0], "tiles": full_tiles[1]}),
             "fast_nms_timed_region": entry("fast_nms", alg["fast_nms"] * work_frac, roof_ms["fast_nms"], "k_fast3",
@@ -489,13 +514,19 @@ def main():
                                             "note": "early exit on (production): bytes charged = tiles that worked / all tiles x 1 B/px"}),
             "select": entry("select", 0, stage_ms["select"] + stage_ms["compact"] + stage_ms["harris"], "k_level_select"),
             "describe": entry("describe", 0, stage_ms["describe"], "k_describe2"),
-        }
-        # headline: the slower of the two roofline kernels, FAST with every tile working
-        dom = "blur" if roof_ms["blur"] >= full_ms["fast_nms"] else "fast_nms_full_work"
-        dom_ms = kern[dom]["avg_launch_ms"]
-        achieved = gbs(kern[dom]["algorithmic_bytes_per_launch"], dom_ms)
-        both_full = gbs(alg["blur"] + alg["fast_nms"], roof_ms["blur"] + full_ms["fast_nms"])
-        both_timed = gbs(alg["blur"] + alg["fast_nms"] * work_frac, roof_ms["blur"] + roof_ms["fast_nms"])
+        })
+        blur_ms = (unfused_ms or stage_ms)["blur"] if fused else roof_ms["blur"]
+        # headline: the kernel of the two roofline stages (blur, FAST) that is furthest below the roof: FAST with
+        # EVERY tile working (its early exit moves no bytes for the tiles it skips, so only this figure is a
+        # bandwidth fraction); blur is the stand-alone kernel
+        fracs = {"fast_nms_full_work": gbs(alg["fast_nms"], full_ms["fast_nms"])}
+        if blur_ms > 0:
+            fracs["blur_alone"] = gbs(alg["blur"], blur_ms)
+        dom = min(fracs, key=lambda k: fracs[k] if fracs[k] > 0 else 1e30)
+        dom_ms = kern[dom]["avg_launch_ms"] if dom in kern else full_ms["fast_nms"]
+        achieved = fracs[dom]
+        both_full = gbs(alg["blur"] + alg["fast_nms"], blur_ms + full_ms["fast_nms"])
+        both_timed = gbs(alg["blur"] + alg["fast_nms"] * work_frac, blur_ms + roof_ms["fast_nms"])
         out = {
             "metric": "ORB detect+describe frames/sec (1241x376, 8 lvls)" if args.workload == "kitti"
                       else "ORB detect+describe frames/sec (1920x1080, 12 lvls)",
@@ -504,11 +535,11 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl, "frames_per_step_per_gpu": B, "distinct_resident_batches": len(batches),
                        "sharding": "frame-parallel, no data-path collective",
-                       "fast_early_exit": not args.full_work},
-            "roofline": {"bound": "hbm", "kernel": "k_blur3" if dom == "blur" else "k_fast3 (every tile working)",
+                       "fast_early_exit": not args.full_work, "pyramid_blur_fused": not args.unfused},
+            "roofline": {"bound": "hbm", "kernel": "k_blur3 (stand-alone)" if dom == "blur_alone" else "k_fast3 (every tile working)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": kern[dom].get("hbm_traffic_bytes_per_launch"),
-                         "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes_per_launch"],
+                         "traffic": kern.get(dom, {}).get("hbm_traffic_bytes_per_launch"),
+                         "algorithmic_bytes_per_launch": alg["blur"] if dom == "blur_alone" else alg["fast_nms"],
                          "avg_launch_ms": dom_ms,
                          "residency": "batch %d: pools %.0f MB, %s the 256 MiB Infinity Cache" % (
                              B, 2 * 1.05 * pyr_px * B / 1e6 + W * H * B / 1e6,
@@ -521,6 +552,7 @@ def main():
             "fast_tiles": {"full_work": fast_tiles[0], "total": fast_tiles[1], "early_exit_frac": 1.0 - work_frac},
             "stage_ms_per_step": stage_ms,
             "stage_ms_per_step_fast_full_work": full_ms,
+            "stage_ms_per_step_unfused": unfused_ms,
             "fps_with_d2h": fps_d2h, "fps_with_d2h_blocking_fetch": fps_d2h_blocking,
             "fps_two_contexts_alternating": two_ctx_fps,
             "single_frame_host_to_host": single,

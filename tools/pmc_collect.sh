@@ -1,0 +1,58 @@
+#!/bin/bash
+# rocprofv3 evidence for profiles/r02 (run on the GPU box: bash tools/pmc_collect.sh).
+#   kernel-trace --stats and the PMC passes are SEPARATE runs (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2:
+#   /opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots"); the program after `--` is python3 itself.
+# Configurations of bench.py (--only-timed: nothing but the timed region runs, so the per-kernel averages
+# describe exactly that configuration):
+#   timed      production: pyramid+blur fused, FAST early exit on
+#   fullwork   FAST with every tile working (--full-work)
+#   unfused    separate pyramid and blur kernels (--unfused)
+set -e
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+O=gpurun_out/r02
+mkdir -p $O
+B="bench.py --only-timed --no-cpu-baseline --steps 10 --warmup 2"
+run() {  # name, rocprof args..., -- bench args
+  local name=$1; shift
+  echo "== $name: $*" >> $O/log.txt
+  rocprofv3 "$@" >> $O/log.txt 2>&1 || echo "FAILED $name" >> $O/log.txt
+  echo "$name done"
+}
+SQA="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
+SQB="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM"
+for cfg in timed fullwork unfused; do
+  case $cfg in
+    timed) X="";;
+    fullwork) X="--full-work";;
+    unfused) X="--unfused";;
+  esac
+  run ${cfg}_stats --kernel-trace --stats -d $O/${cfg}_stats -o run --output-format csv -- python3 $B $X
+  run ${cfg}_sqa --kernel-trace --pmc $SQA -d $O/${cfg}_sqa -o run --output-format csv -- python3 $B $X
+  run ${cfg}_sqb --kernel-trace --pmc $SQB -d $O/${cfg}_sqb -o run --output-format csv -- python3 $B $X
+  run ${cfg}_fetch --kernel-trace --pmc FETCH_SIZE -d $O/${cfg}_fetch -o run --output-format csv -- python3 $B $X
+  run ${cfg}_write --kernel-trace --pmc WRITE_SIZE -d $O/${cfg}_write -o run --output-format csv -- python3 $B $X
+done
+# past the 256 MiB Infinity Cache: 512 frames per step (pools ~1.8 GB)
+B512="bench.py --only-timed --no-cpu-baseline --batch 512 --rotate 1 --steps 4 --warmup 1"
+for cfg in timed fullwork unfused; do
+  case $cfg in
+    timed) X="";;
+    fullwork) X="--full-work";;
+    unfused) X="--unfused";;
+  esac
+  run b512_${cfg}_stats --kernel-trace --stats -d $O/b512_${cfg}_stats -o run --output-format csv -- python3 $B512 $X
+done
+run b512_timed_fetch --kernel-trace --pmc FETCH_SIZE -d $O/b512_timed_fetch -o run --output-format csv -- python3 $B512
+run b512_timed_write --kernel-trace --pmc WRITE_SIZE -d $O/b512_timed_write -o run --output-format csv -- python3 $B512
+# FETCH_SIZE / WRITE_SIZE calibration on known byte counts, per access width (tools/bw_probe.hip)
+if [ -x tools/bw_probe.bin ]; then
+  for mb in 97 1600; do
+    ./tools/bw_probe.bin $mb > $O/bw_probe_$mb.txt 2>&1
+    run calib_fetch_$mb --kernel-trace --pmc FETCH_SIZE -d $O/calib_fetch_$mb -o run --output-format csv -- ./tools/bw_probe.bin $mb
+    run calib_write_$mb --kernel-trace --pmc WRITE_SIZE -d $O/calib_write_$mb -o run --output-format csv -- ./tools/bw_probe.bin $mb
+  done
+fi
+python3 tools/pmc_to_json.py $O profiles/r02 > $O/summary.txt 2>&1 || true
+tail -5 $O/summary.txt
