@@ -9,8 +9,9 @@ Rank 0 prints ONE JSON line.
 Workload (BASELINE.json configs[1], batched as configs[2]): KITTI-shaped 1241x376 8-bit frames,
 8 pyramid levels, scale 1.2, 1000 features, FAST-9 threshold 20, 3x3 NMS, Harris top-N, orientation
 patch 31, rotated BRIEF-256, 5x5 Gaussian blur on every level.  A "step" = one pass of the whole
-path over one batch of --batch (default 64) synthetic frames that are already resident in HBM; the
-steps rotate over --rotate (default 4) DISTINCT resident batches.  Results stay resident in HBM too
+path over one batch of --batch (default 256) synthetic frames that are already resident in HBM; the
+steps rotate over --rotate (default 2) DISTINCT resident batches, so the pools of a step (~0.9 GB) and
+its inputs lie far beyond the 256 MiB Infinity Cache: every kernel streams from and to HBM.  Results stay resident in HBM too
 (the D2H-inclusive rate is reported beside it as `fps_with_d2h`, it is never `value`).
 
 Frames are independent, so ranks shard the stream with NO data-path collective (weak scaling: every
@@ -197,8 +198,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
-    ap.add_argument("--rotate", type=int, default=4, help="distinct resident input batches the steps rotate over")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU (resident in HBM)")
+    ap.add_argument("--rotate", type=int, default=2, help="distinct resident input batches the steps rotate over")
     ap.add_argument("--workload", default="kitti", choices=["kitti", "1080p"])
     ap.add_argument("--stream-frames", type=int, default=0,
                     help="config 3: a stream of 8*F frames split over the ranks, each rank walks its block once")
@@ -470,7 +471,9 @@ def main():
         # ---- roofline.  Algorithmic bytes (SURVEY.md §8d / BASELINE.md §4): blur 2 B/px, FAST 1 B/px over all
         # pyramid pixels; pyramid = level 0 read + every level written; per launch = per frame x batch.
         alg = {"pyramid": (W * H + pyr_px) * B, "blur": 2.0 * pyr_px * B, "fast_nms": 1.0 * pyr_px * B}
-        pmc = load_pmc(args.pmc_file) if (args.workload == "kitti" and B == 64) else None
+        pmc = load_pmc(args.pmc_file) if args.workload == "kitti" else None
+        if pmc and pmc.get("batch") != B:
+            pmc = None  # counters per launch of another batch size
 
         def gbs(nbytes, ms):
             return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0

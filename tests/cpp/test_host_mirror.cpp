@@ -258,6 +258,19 @@ int main(int argc, char** argv) {
     EXPECT(back.size() > pts2.size() / 2, "backward tracking lost too many points");
     std::printf("LKTracker: %zu of %zu points tracked, %d consistent with the shift, %zu tracked back\n", pts2.size(),
                 pts0.size(), shift_ok, back.size());
+    // a frame with NO points (the VO loop's fallback produced none) still advances the cached previous
+    // frame: after (empty -> img2), tracking pts0 with prev == nullptr into `image` must equal tracking
+    // them with prev = img2 given explicitly
+    {
+      std::vector<orbx::Point2f> none, none2;
+      orbx::track_optical_flow(lk, nullptr, img2, none, none2);  // the tracker's "previous" is now img2
+      std::vector<orbx::Point2f> a1 = pts0, a2, b1 = pts0, b2;
+      orbx::track_optical_flow(lk, nullptr, image, a1, a2);
+      orbx::LKTracker fresh;
+      orbx::track_optical_flow(fresh, &img2, image, b1, b2);
+      EXPECT(a2.size() == b2.size() && !a2.empty() && std::memcmp(a2.data(), b2.data(), a2.size() * 8) == 0,
+             "cached previous frame lags after an empty-points call (%zu vs %zu tracks)", a2.size(), b2.size());
+    }
   }
   std::printf(fails ? "FAILED (%d)\n" : "OK\n", fails);
   return fails ? 1 : 0;

@@ -13,7 +13,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=gpurun_out/r02
 mkdir -p $O
-B="bench.py --only-timed --no-cpu-baseline --steps 10 --warmup 2"
+B="bench.py --only-timed --no-cpu-baseline --steps 10 --warmup 2"   # bench.py's default workload: 256 frames per launch
+B64="bench.py --only-timed --no-cpu-baseline --batch 64 --rotate 4 --steps 10 --warmup 2"  # BASELINE.json configs[2]
 run() {  # name, rocprof args..., -- bench args
   local name=$1; shift
   echo "== $name: $*" >> $O/log.txt
@@ -34,7 +35,8 @@ for cfg in timed fullwork unfused; do
   run ${cfg}_fetch --kernel-trace --pmc FETCH_SIZE -d $O/${cfg}_fetch -o run --output-format csv -- python3 $B $X
   run ${cfg}_write --kernel-trace --pmc WRITE_SIZE -d $O/${cfg}_write -o run --output-format csv -- python3 $B $X
 done
-# past the 256 MiB Infinity Cache: 512 frames per step (pools ~1.8 GB)
+# kernel durations at 64 frames per launch (BASELINE.json configs[2]; pools inside the Infinity Cache) and at
+# 512 (pools ~1.8 GB)
 B512="bench.py --only-timed --no-cpu-baseline --batch 512 --rotate 1 --steps 4 --warmup 1"
 for cfg in timed fullwork unfused; do
   case $cfg in
@@ -42,10 +44,9 @@ for cfg in timed fullwork unfused; do
     fullwork) X="--full-work";;
     unfused) X="--unfused";;
   esac
+  run b64_${cfg}_stats --kernel-trace --stats -d $O/b64_${cfg}_stats -o run --output-format csv -- python3 $B64 $X
   run b512_${cfg}_stats --kernel-trace --stats -d $O/b512_${cfg}_stats -o run --output-format csv -- python3 $B512 $X
 done
-run b512_timed_fetch --kernel-trace --pmc FETCH_SIZE -d $O/b512_timed_fetch -o run --output-format csv -- python3 $B512
-run b512_timed_write --kernel-trace --pmc WRITE_SIZE -d $O/b512_timed_write -o run --output-format csv -- python3 $B512
 # FETCH_SIZE / WRITE_SIZE calibration on known byte counts, per access width (tools/bw_probe.hip)
 if [ -x tools/bw_probe.bin ]; then
   for mb in 97 1600; do

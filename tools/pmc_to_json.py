@@ -42,9 +42,12 @@ def main():
     os.makedirs(dst, exist_ok=True)
     import bench
 
-    res = {"source_sha": bench.kernel_source_sha(), "workload": "bench.py default: KITTI 1241x376, 8 levels, batch 64",
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+    res = {"source_sha": bench.kernel_source_sha(), "batch": batch,
+           "workload": "bench.py default: KITTI 1241x376, 8 levels, %d frames per launch" % batch,
            "kernels": {}, "configs": {}}
-    for cfg in ("timed", "fullwork", "unfused", "b512_timed", "b512_fullwork", "b512_unfused"):
+    for cfg in ("timed", "fullwork", "unfused", "b64_timed", "b64_fullwork", "b64_unfused", "b512_timed", "b512_fullwork",
+                "b512_unfused"):
         st = trace_stats(os.path.join(src, cfg + "_stats"))
         if not st:
             continue

@@ -12,7 +12,10 @@
 //     src/feature_matching.cpp:295-322): plain `ostream << double`, 6 significant digits.
 // OpenCV (imread) is absent from the image this was written in, so the PNG reader is written
 // against the PNG specification directly on top of zlib: non-interlaced, 8-bit gray (the KITTI
-// format), gray+alpha, RGB and RGBA (converted with cv::imread's fixed-point BT.601 weights).
+// format), gray+alpha, RGB and RGBA (converted with cv::cvtColor's fixed-point BT.601 weights).
+// PARITY UNPINNED for colour PNGs: cv::imread(IMREAD_GRAYSCALE) lets libpng convert (png_set_rgb_to_gray),
+// whose coefficients and rounding differ from cvtColor's in the last bit; KITTI frames are 8-bit gray
+// and are not affected (pinned by the reference's own 000000.png, tests/test_kitti_io.py).
 // Link with -lz.  Nothing here touches the GPU; frames go to liborbx as orbx::Image.
 #pragma once
 #include <zlib.h>

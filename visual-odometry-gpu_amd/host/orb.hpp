@@ -587,7 +587,13 @@ struct TermCriteria {  // cv::TermCriteria(COUNT + EPS, maxCount, epsilon)
 
 class LKTracker {
  public:
-  LKTracker() : ctx_(detail::stage_ctx()) {}
+  // the tracker owns its context: the pyramid of the previous frame is cached in it, and a free stage
+  // function called on a larger image re-creates the shared stage context (which would drop that cache)
+  LKTracker() : ctx_([] {
+    orbx_params p = detail::gpu_defaults();
+    p.nlevels = 1;
+    return std::make_shared<detail::Ctx>(p);
+  }()) {}
   // prevImg == nullptr: the previous call's nextImg is this call's prevImg (its pyramid is still on the
   // device): the `img1 = img2.clone()` of the reference's loop, src/feature_tracking.cpp:112
   void calcOpticalFlowPyrLK(const Image* prevImg, const Image& nextImg, const std::vector<Point2f>& prevPts,
@@ -596,7 +602,7 @@ class LKTracker {
     if (winSize.width != winSize.height) throw std::runtime_error("calcOpticalFlowPyrLK: square windows only");
     if (prevImg && (prevImg->width != nextImg.width || prevImg->height != nextImg.height))
       throw std::runtime_error("calcOpticalFlowPyrLK: image sizes differ");
-    orbx_ctx* c = ctx_->get(8, 8);
+    orbx_ctx* c = ctx_->get(nextImg.width, nextImg.height);
     const int n = (int)prevPts.size();
     nextPts.resize(prevPts.size());
     status.resize(prevPts.size());
@@ -617,10 +623,12 @@ class LKTracker {
 // VisualOdom::track_optical_flow (src/feature_tracking.cpp:166-193): track pts1 into img2, drop lost tracks
 inline void track_optical_flow(LKTracker& lk, const Image* img1, const Image& img2, std::vector<Point2f>& pts1,
                                std::vector<Point2f>& pts2) {
-  if (pts1.empty()) return;
   std::vector<uint8_t> status;
   std::vector<float> err;
+  // also with no points: the call uploads img2, so that the tracker's cached "previous frame" stays
+  // in step with the caller's loop (img1 == nullptr on the next call means THIS img2)
   lk.calcOpticalFlowPyrLK(img1, img2, pts1, pts2, status, err, Size(21, 21), 3, TermCriteria(30, 0.01));
+  if (pts1.empty()) return;
   std::vector<Point2f> v1, v2;
   for (size_t i = 0; i < status.size(); i++)
     if (status[i]) {
