@@ -370,7 +370,7 @@ void build_pyrblur_tiles(const OrbxPlan& plan, std::vector<OrbxTileDesc>* out) {
   for (int l = 0; l < plan.nlevels; l++) {
     const OrbxLevel& L = plan.L[l];
     const int ntx = (L.pitch + ORBX_PYRBLUR_TW - 1) / ORBX_PYRBLUR_TW;  // the padding bytes are (re)written as zeros
-    const int nb = (L.h + ORBX_BLUR3_RH - 1) / ORBX_BLUR3_RH, rows = (L.h + nb - 1) / nb;
+    const int nb = (L.h + ORBX_PYRBLUR_RH - 1) / ORBX_PYRBLUR_RH, rows = (L.h + nb - 1) / nb;
     for (int b = 0; b < nb; b++)
       for (int tx = 0; tx < ntx; tx++) {
         OrbxTileDesc d{};

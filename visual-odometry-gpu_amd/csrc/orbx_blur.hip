@@ -216,10 +216,15 @@ struct __attribute__((packed, aligned(1))) uint2_unaligned {
 };
 
 struct PyrSrc {
-  const uint8_t* src;  // level 0 = the input frame
+  __amdgpu_buffer_rsrc_t rsrc;  // the input frame (= level 0), exactly its bytes
+  const uint8_t* src;
   int in_stride, w0, h0;
-  const OrbxResizeTap* ytaps;  // y taps of this level
-  int x, w, h;                 // lane x, level size
+  int x, w, h;                  // lane x, level size
+  // y taps of the strip's input rows: lane r holds the tap of input row r (level row reflect(y0 - 2 + r)),
+  // fetched once per strip with ONE vector load and handed out with v_readlane -- a scalar load per row
+  // (plus its wait) sat in front of every row's gathers
+  int yt_ofs;
+  uint32_t yt_cc;               // c0 | c1 << 16
 };
 struct PyrLane {  // x taps of the lane's four pixels
   uint32_t ofs[4], cc[4], sel[4], base;
@@ -233,33 +238,36 @@ struct PyrRaw {
   int b0, b1;
 };
 
-// issue the loads of output row yl (already reflected into [0, h))
+// issue the loads of input row r of the strip (level row yl = reflect(y0 - 2 + r)).  The row offsets are
+// scalars (buffer loads: frame descriptor + scalar row offset + the lane's constant byte offset), no
+// 64-bit per-lane address arithmetic.
 template <int MODE>
-__device__ __forceinline__ void pyr_issue(const PyrSrc& P, const PyrLane& T, int yl, PyrRaw<MODE>& R) {
+__device__ __forceinline__ void pyr_issue(const PyrSrc& P, const PyrLane& T, int r, int yl, PyrRaw<MODE>& R) {
   if (MODE == 0) {
-    const uint8_t* row = P.src + (size_t)yl * P.in_stride;
     const int nvalid = P.w - P.x;
     uint32_t v = 0;
     if (P.x >= 0 && (nvalid >= 4 || (nvalid > 0 && yl + 1 < P.h))) {
       // (a partial last dword of a row above the last one runs into the next row of the same
       // frame: readable, the blur's column patch / byte mask ignores those bytes)
-      v = *reinterpret_cast<const u32_unaligned*>(row + P.x);
+      v = __builtin_amdgcn_raw_buffer_load_b32(P.rsrc, (uint32_t)P.x, yl * P.in_stride, 0);
     } else if (P.x >= 0 && nvalid > 0) {  // last dword of the last row: never read past the frame
+      const uint8_t* row = P.src + (size_t)yl * P.in_stride;
       for (int k = 0; k < nvalid; k++) v |= (uint32_t)row[P.x + k] << (8 * k);
     }
     R.q0[0] = v;
     R.b0 = R.b1 = 0;
     return;
   }
-  const OrbxResizeTap ty = P.ytaps[yl];  // wave-uniform -> scalar load
-  const int sy0 = min(max(ty.ofs, 0), P.h0 - 1), sy1 = min(max(ty.ofs + 1, 0), P.h0 - 1);
-  const uint8_t* S0 = P.src + (size_t)sy0 * P.in_stride;
-  const uint8_t* S1 = P.src + (size_t)sy1 * P.in_stride;
-  R.b0 = ty.c0;
-  R.b1 = ty.c1;
+  const int tofs = __builtin_amdgcn_readlane(P.yt_ofs, r);
+  const uint32_t tcc = (uint32_t)__builtin_amdgcn_readlane((int)P.yt_cc, r);
+  const int sy0 = min(max(tofs, 0), P.h0 - 1), sy1 = min(max(tofs + 1, 0), P.h0 - 1);
+  const int so0 = sy0 * P.in_stride, so1 = sy1 * P.in_stride;
+  R.b0 = (int)(tcc & 0xffffu);
+  R.b1 = (int)(tcc >> 16);
   if (MODE == 1) {
-    const uint2_unaligned a = *reinterpret_cast<const uint2_unaligned*>(S0 + T.base);
-    const uint2_unaligned b = *reinterpret_cast<const uint2_unaligned*>(S1 + T.base);
+    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+    const v2u a = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(P.rsrc, T.base, so0, 0));
+    const v2u b = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(P.rsrc, T.base, so1, 0));
     R.q0[0] = a.x;
     R.q0[1] = a.y;
     R.q1[0] = b.x;
@@ -268,8 +276,8 @@ __device__ __forceinline__ void pyr_issue(const PyrSrc& P, const PyrLane& T, int
 #pragma unroll
     for (int k = 0; k < (MODE == 2 ? 4 : 0); k++) {
       // ofs <= w0-2 always (host table): one unaligned 16-bit load fetches src[ofs], src[ofs+1]
-      R.q0[k] = *reinterpret_cast<const u16_unaligned*>(S0 + T.ofs[k]);
-      R.q1[k] = *reinterpret_cast<const u16_unaligned*>(S1 + T.ofs[k]);
+      R.q0[k] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(P.rsrc, T.ofs[k], so0, 0);
+      R.q1[k] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(P.rsrc, T.ofs[k], so1, 0);
     }
   }
 }
@@ -317,7 +325,10 @@ __device__ __forceinline__ void pyrblur_strip(const Blur3Strip& S, const PyrSrc&
   // input row r of the strip is level row y0 - 2 + r; output row y0 + r - 4 is complete after row r
   const int nr = S.yend - S.y0 + 4;  // input rows
   // (rows past the strip, in the last group, are computed from clamped indices and never stored)
-  auto issue = [&](int r, PyrRaw<MODE>& R) { pyr_issue<MODE>(P, T, reflect101_s(S.y0 - 2 + min(r, nr + 1), S.h), R); };
+  auto issue = [&](int r, PyrRaw<MODE>& R) {
+    const int rr = min(r, nr + 1);
+    pyr_issue<MODE>(P, T, rr, reflect101_s(S.y0 - 2 + rr, S.h), R);
+  };
   auto hpass = [&](int rb, int k) {
     if (MODE == 2 && k < 4) issue(rb + k + 1, raw[(k + 1) & 1]);
     blur3_h<PATCH>(S, pyr_finish<MODE>(T, raw[MODE == 2 ? (k & 1) : k]), 0u, k4, k6, he[k], ho[k]);
@@ -389,13 +400,20 @@ __global__ __launch_bounds__(256, 8) void k_pyrblur(const OrbxTileDesc* __restri
 
   PyrSrc P;
   P.src = in + (size_t)f * in_frame_stride;
+  P.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(P.src), 0, in_stride * (h0 - 1) + w0, 0x00020000);
   P.in_stride = in_stride;
   P.w0 = w0;
   P.h0 = h0;
-  P.ytaps = taps + d.u1;
   P.x = x;
   P.w = w;
   P.h = h;
+  P.yt_ofs = 0;
+  P.yt_cc = 0;
+  if (d.l > 0) {  // lane r: the y tap of the strip's input row r (a band has at most 58 rows: r <= 63)
+    const OrbxResizeTap ty = taps[d.u1 + reflect101_s(S.y0 - 2 + min(lane, S.yend - S.y0 + 5), h)];
+    P.yt_ofs = ty.ofs;
+    P.yt_cc = (uint32_t)(uint16_t)ty.c0 | ((uint32_t)(uint16_t)ty.c1 << 16);
+  }
   PyrLane T;
 #pragma unroll
   for (int k = 0; k < 4; k++) T.ofs[k] = T.cc[k] = T.sel[k] = 0;

@@ -112,6 +112,8 @@ constexpr int orbx_fast3_tile_h(int nms_radius) {
 #define ORBX_BLUR3_RH 64
 // fused pyramid + blur: the halo dwords are computed, not loaded, so lanes 0 / 63 are halo-only
 #define ORBX_PYRBLUR_TW 248
+// rows per band of the fused kernel: the y taps of a band's input rows (rows + 6) sit one per lane
+#define ORBX_PYRBLUR_RH 58
 // pyramid kernel: a wave owns 256 x 8 pixels (level 0 and the levels resized through 8-byte
 // windows) or 256 x 4, a workgroup four times that; OrbxTileDesc::f carries the rows per wave
 #define ORBX_PYR2_TW 256
