@@ -47,7 +47,18 @@ for cfg in timed fullwork unfused; do
   run b64_${cfg}_stats --kernel-trace --stats -d $O/b64_${cfg}_stats -o run --output-format csv -- python3 $B64 $X
   run b512_${cfg}_stats --kernel-trace --stats -d $O/b512_${cfg}_stats -o run --output-format csv -- python3 $B512 $X
 done
+# BASELINE.json configs[4]: 1920x1080, 12 levels, 4000 features
+run hd_timed_stats --kernel-trace --stats -d $O/hd_timed_stats -o run --output-format csv -- python3 bench.py --workload 1080p --batch 32 --rotate 2 --steps 6 --warmup 1 --only-timed --no-cpu-baseline
+run hd_fullwork_stats --kernel-trace --stats -d $O/hd_fullwork_stats -o run --output-format csv -- python3 bench.py --workload 1080p --batch 32 --rotate 2 --steps 6 --warmup 1 --only-timed --no-cpu-baseline --full-work
+# plain bench lines (no profiler): the default line, configs[2] (64 frames per step), configs[3] at N = 1
+# (8 x 1000-frame stream walked once), configs[4]
+python3 bench.py > $O/bench_default.json 2>> $O/log.txt || echo "FAILED bench_default" >> $O/log.txt
+python3 bench.py --batch 64 --rotate 4 --no-cpu-baseline > $O/bench_batch64.json 2>> $O/log.txt || echo "FAILED bench_batch64" >> $O/log.txt
+python3 bench.py --stream-frames 1000 --no-cpu-baseline > $O/bench_stream_8000.json 2>> $O/log.txt || echo "FAILED bench_stream" >> $O/log.txt
+python3 bench.py --workload 1080p --batch 32 --rotate 2 --steps 10 --no-cpu-baseline > $O/bench_1080p.json 2>> $O/log.txt || echo "FAILED bench_1080p" >> $O/log.txt
+echo "bench lines done"
 # FETCH_SIZE / WRITE_SIZE calibration on known byte counts, per access width (tools/bw_probe.hip)
+[ -x tools/bw_probe.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/bw_probe.bin tools/bw_probe.hip >> $O/log.txt 2>&1 || true
 if [ -x tools/bw_probe.bin ]; then
   for mb in 97 1600; do
     ./tools/bw_probe.bin $mb > $O/bw_probe_$mb.txt 2>&1

@@ -47,7 +47,7 @@ def main():
            "workload": "bench.py default: KITTI 1241x376, 8 levels, %d frames per launch" % batch,
            "kernels": {}, "configs": {}}
     for cfg in ("timed", "fullwork", "unfused", "b64_timed", "b64_fullwork", "b64_unfused", "b512_timed", "b512_fullwork",
-                "b512_unfused"):
+                "b512_unfused", "hd_timed", "hd_fullwork"):
         st = trace_stats(os.path.join(src, cfg + "_stats"))
         if not st:
             continue
@@ -89,6 +89,11 @@ def main():
             e["traffic_bytes"] = (2.0 * fe + wr) * 1024.0
         res["kernels"][name] = e
     json.dump(res, open(os.path.join(dst, "pmc_counters.json"), "w"), indent=1, sort_keys=True)
+    for name in ("bench_default", "bench_batch64", "bench_stream_8000", "bench_1080p", "bw_probe_97", "bw_probe_1600"):
+        for ext in (".json", ".txt"):
+            f = os.path.join(src, name + ext)
+            if os.path.exists(f) and os.path.getsize(f) > 0:
+                open(os.path.join(dst, name + ext), "w").write(open(f).read())
     for name, e in res["kernels"].items():
         print(name, e)
     print("calibration", json.dumps(calib)[:2000])

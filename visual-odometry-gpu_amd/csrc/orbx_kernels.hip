@@ -1380,13 +1380,15 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
     }
   }
   __syncthreads();
-  // trig: one thread per keypoint (moments are exact integers < 2^24, so the
-  // reference's float accumulation equals them; atan2f(0,0) = 0 covers the border case)
-  if (tid < DESC_KPB && slot0 + tid < count) {
-    const float angle = orbx_atan2f((float)s_m[tid][1], (float)s_m[tid][0]);
-    s_cs[tid][0] = orbx_cosf(angle);
-    s_cs[tid][1] = orbx_sinf(angle);
-    out_angle[fo + slot0 + tid] = angle;
+  // trig: TWO threads per keypoint -- both compute the angle, then the even one its cosine and the odd
+  // one its sine through the shared sincosf body (one pass through its two polynomial branches
+  // instead of two).  Moments are exact integers < 2^24, so the reference's float accumulation
+  // equals them; atan2f(0,0) = 0 covers the border case.
+  if (tid < 2 * DESC_KPB && slot0 + (tid >> 1) < count) {
+    const int q = tid >> 1, want_sin = tid & 1;
+    const float angle = orbx_atan2f((float)s_m[q][1], (float)s_m[q][0]);
+    s_cs[q][want_sin] = orbx_sincosf_impl(angle, want_sin ^ 1);
+    if (!want_sin) out_angle[fo + slot0 + q] = angle;
   }
   __syncthreads();
 
