@@ -394,11 +394,12 @@ def main():
         submit(0)
         ctx.batch_prefetch()
         t1 = time.perf_counter()
-        done = 0
+        done = kp_seen = 0
         for i in range(1, nd + 1):
             n = submit(i)
-            r_prev = ctx.batch_fetch(0, batches[(i - 1) % len(batches)][1], cap, previous=True)
-            done += len(r_prev["counts"])
+            hv = ctx.batch_host_view(previous=True)  # batch i-1, zero-copy from the pinned mirror
+            done += len(hv["counts"])
+            kp_seen += int(hv["counts"].sum())
             ctx.batch_prefetch()
         ctx.wait()
         fps_d2h = world * done / (time.perf_counter() - t1)

@@ -162,6 +162,12 @@ int orbx_batch_fetch(orbx_ctx* ctx, int first, int n, int32_t* counts, orbx_keyp
  * mirror on the context's copy stream; orbx_batch_fetch / _previous then wait for that copy
  * instead of copying.  The results of batch i must be fetched before batch i+2 is submitted. */
 int orbx_batch_prefetch(orbx_ctx* ctx);
+/* Zero-copy host view of a result block: pointers into the context's PINNED mirror of the last batch
+ * (previous = 0) or of the batch before it (previous = 1), same layout as the device view (fixed
+ * stride `slot_capacity` entries per frame; only the first counts[f] entries of frame f are valid).
+ * Waits for the block's copy (starts it if orbx_batch_prefetch was not called).  The view stays valid
+ * until the block is written again, i.e. until the second batched call after the one it belongs to. */
+int orbx_batch_results_host(orbx_ctx* ctx, int previous, orbx_batch_view* view);
 int orbx_batch_fetch_previous(orbx_ctx* ctx, int first, int n, int32_t* counts, orbx_keypoint* keypoints,
                               float* orientations, orbx_descriptor* descriptors, float* responses, int32_t* levels,
                               orbx_keypoint* level_kps, int capacity);

@@ -481,6 +481,14 @@ def test_pipelined_result_fetch(pkg, kitti0, kitti1):
             for g, w in zip(got, want):
                 for k in keys:
                     assert np.array_equal(g[k], w[k]), k
+            # zero-copy views of the pinned mirrors: the last batch and the one before it
+            hv, hp = c.batch_host_view(), c.batch_host_view(previous=True)
+            for v_, w in ((hv, want[-1]), (hp, want[-2])):
+                assert np.array_equal(v_["counts"], w["counts"])
+                for f_ in range(2):
+                    n_ = int(w["counts"][f_])
+                    for k in keys[1:]:
+                        assert np.array_equal(v_[k][f_, :n_], w[k][f_, :n_]), k
         with pytest.raises(pkg.OrbxError):
             pkg.Context(p).batch_fetch(0, 1, cap, previous=True)  # nothing has run yet
 

@@ -1214,6 +1214,34 @@ int orbx_batch_fetch(orbx_ctx* c, int first, int n, int32_t* counts, orbx_keypoi
                      capacity);
 }
 
+int orbx_batch_results_host(orbx_ctx* c, int previous, orbx_batch_view* v) {
+  DeviceGuard _dg(c);
+  if (!c || !v) return ORBX_ERR_INVALID_ARG;
+  const int b = previous ? (c->blk ^ 1) : c->blk;
+  if (c->nb[b] <= 0) return fail(c, ORBX_ERR_INVALID_ARG, previous ? "there is no batch before the last one" : "no batch has been run");
+  const OutLayout& o = c->layoutb[b];
+  if (c->copy_pending[b]) {
+    HIPCHK(c, hipEventSynchronize(c->ev_copied[b]));
+  } else {
+    HIPCHK(c, hipStreamWaitEvent(c->cstream, c->ev_done[b], 0));
+    HIPCHK(c, hipMemcpyAsync(c->h_outb[b], c->d_outb[b], o.total, hipMemcpyDeviceToHost, c->cstream));
+    HIPCHK(c, hipEventRecord(c->ev_copied[b], c->cstream));
+    c->copy_pending[b] = true;
+    HIPCHK(c, hipEventSynchronize(c->ev_copied[b]));
+  }
+  const uint8_t* h = c->h_outb[b];
+  v->counts = (const int32_t*)(h + o.counts);
+  v->keypoints = (const orbx_keypoint*)(h + o.kp);
+  v->level_kps = (const orbx_keypoint*)(h + o.lkp);
+  v->orientations = (const float*)(h + o.angle);
+  v->responses = (const float*)(h + o.resp);
+  v->levels = (const int32_t*)(h + o.level);
+  v->descriptors = (const orbx_descriptor*)(h + o.desc);
+  v->slot_capacity = c->capb[b];
+  v->n = c->nb[b];
+  return ORBX_OK;
+}
+
 int orbx_batch_prefetch(orbx_ctx* c) {
   DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;

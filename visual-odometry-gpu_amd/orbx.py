@@ -27,7 +27,7 @@ EXPORTS = [
     "orbx_params_default_gpu", "orbx_params_default_cpu", "orbx_create", "orbx_destroy",
     "orbx_last_error_string", "orbx_status_string", "orbx_version", "orbx_get_plan",
     "orbx_detect_and_compute", "orbx_detect_and_compute_batch_device", "orbx_detect_and_compute_batch_host",
-    "orbx_wait", "orbx_batch_results_device", "orbx_batch_fetch", "orbx_batch_prefetch",
+    "orbx_wait", "orbx_batch_results_device", "orbx_batch_results_host", "orbx_batch_fetch", "orbx_batch_prefetch",
     "orbx_batch_fetch_previous", "orbx_enable_stage_timing",
     "orbx_last_stage_times", "orbx_stage_times_history", "orbx_bench_stage", "orbx_set_fast_early_exit",
     "orbx_set_fused_pyramid_blur", "orbx_fast_tile_counts", "orbx_lk_track", "orbx_lk_pyramid_levels", "orbx_fast_score", "orbx_nms", "orbx_fast",
@@ -238,6 +238,21 @@ class Context:
         v = BatchView()
         self._chk(self._lib.orbx_batch_results_device(self._h, C.byref(v)))
         return v
+
+    def batch_host_view(self, previous=False):
+        """Zero-copy numpy views of the pinned host mirror of a result block (orbx_batch_results_host)."""
+        v = BatchView()
+        self._chk(self._lib.orbx_batch_results_host(self._h, 1 if previous else 0, C.byref(v)))
+        n, cap = v.n, v.slot_capacity
+
+        def arr(ptr, dtype, shape):
+            size = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            return np.frombuffer((C.c_char * size).from_address(ptr), dtype=dtype).reshape(shape)
+
+        return dict(counts=arr(v.counts, np.int32, (n,)), kps=arr(v.keypoints, np.int32, (n, cap, 2)),
+                    kps_level=arr(v.level_kps, np.int32, (n, cap, 2)), angles=arr(v.orientations, np.float32, (n, cap)),
+                    responses=arr(v.responses, np.float32, (n, cap)), levels=arr(v.levels, np.int32, (n, cap)),
+                    desc=arr(v.descriptors, np.uint8, (n, cap, 32)))
 
     def batch_prefetch(self):
         """Start the asynchronous D2H copy of the last batch's result block (overlaps the next batch)."""
