@@ -89,7 +89,11 @@ struct orbx_ctx {
   OrbxTileDesc* d_tiles_pyr2 = nullptr;
   OrbxTileDesc* d_tiles_pyrblur = nullptr;  // fused pyramid + blur strips
   int pyrblur_tiles_count = 0;
-  size_t tiles_frame_capacity = 0;
+  // the same strips cut into short row bands: few frames per call (the reference's one-frame call shape)
+  // fill the chip only with many short waves, where a large batch wants few tall ones
+  OrbxTileDesc* d_tiles_pyrblur_small = nullptr;
+  int pyrblur_small_count = 0;
+  size_t tiles_frame_capacity = 0, tiles_small_capacity = 0;
   int blur2_tiles_count = 0, pyr2_tiles_count = 0;
   DevBuf s_tiles;  // stage-API tables
   std::vector<OrbxResizeTap> h_taps;
@@ -365,12 +369,12 @@ void build_blur_tiles(const OrbxPlan& plan, std::vector<OrbxTileDesc>* out) {
 
 // strips of the fused pyramid + blur kernel for ONE frame: 248-px strips (the halo dwords are
 // computed by lanes 0 / 63) x balanced row bands, with the level's resize-table fields
-void build_pyrblur_tiles(const OrbxPlan& plan, std::vector<OrbxTileDesc>* out) {
+void build_pyrblur_tiles(const OrbxPlan& plan, int max_rows, std::vector<OrbxTileDesc>* out) {
   out->clear();
   for (int l = 0; l < plan.nlevels; l++) {
     const OrbxLevel& L = plan.L[l];
     const int ntx = (L.pitch + ORBX_PYRBLUR_TW - 1) / ORBX_PYRBLUR_TW;  // the padding bytes are (re)written as zeros
-    const int nb = (L.h + ORBX_PYRBLUR_RH - 1) / ORBX_PYRBLUR_RH, rows = (L.h + nb - 1) / nb;
+    const int nb = (L.h + max_rows - 1) / max_rows, rows = (L.h + nb - 1) / nb;
     for (int b = 0; b < nb; b++)
       for (int tx = 0; tx < ntx; tx++) {
         OrbxTileDesc d{};
@@ -565,10 +569,14 @@ int set_plan(orbx_ctx* c, int w, int h) {
     if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "blur tile table exceeds pool");
     HIPCHK(c, hipMemcpy(c->d_tiles_blur2, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
     c->blur2_tiles_count = (int)t.size();
-    build_pyrblur_tiles(plan, &t);
+    build_pyrblur_tiles(plan, ORBX_PYRBLUR_RH, &t);
     if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "strip table exceeds pool");
     HIPCHK(c, hipMemcpy(c->d_tiles_pyrblur, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
     c->pyrblur_tiles_count = (int)t.size();
+    build_pyrblur_tiles(plan, ORBX_PYRBLUR_RH_SMALL, &t);
+    if (t.size() > c->tiles_small_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "strip table exceeds pool");
+    HIPCHK(c, hipMemcpy(c->d_tiles_pyrblur_small, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
+    c->pyrblur_small_count = (int)t.size();
     build_frame_tiles(plan, ORBX_PYR2_TW, ORBX_PYR2_TH, true, &t);
     if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "pyramid tile table exceeds pool");
     HIPCHK(c, hipMemcpy(c->d_tiles_pyr2, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
@@ -662,7 +670,10 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
     // blur on every level: pyramid and blur in one pass, the un-blurred pyramid is never materialised
     // (the event slots then read: pyramid = 0, blur = the fused kernel)
     HIPCHK(c, mark(1, true));
-    HIPCHK(c, orbx_launch_pyrblur(s, c->d_tiles_pyrblur, c->pyrblur_tiles_count, P.frame_bytes, P.w0, P.h0, n,
+    // (a wave per strip: below ~4096 waves the chip is far from full and the short-band table wins)
+    const bool small = (long long)n * c->pyrblur_tiles_count < 4096;
+    HIPCHK(c, orbx_launch_pyrblur(s, small ? c->d_tiles_pyrblur_small : c->d_tiles_pyrblur,
+                                  small ? c->pyrblur_small_count : c->pyrblur_tiles_count, P.frame_bytes, P.w0, P.h0, n,
                                   d_frames, row_stride, frame_stride, c->d_taps, c->d_pyr_blur));
   } else {
     HIPCHK(c, launch_pyramid_auto(c, s, n, d_frames, row_stride, frame_stride));
@@ -882,7 +893,7 @@ void orbx_destroy(orbx_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int i = 0; i < orbx_ctx::kGraphs; i++) drop_graph(c, i);
   void* bufs[] = {c->d_in,   c->d_pyr,  c->d_pyr_blur, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total,
-                  c->d_resp, c->d_taps, c->d_gauss,    c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur2, c->d_tiles_pyr2, c->d_tiles_pyrblur,
+                  c->d_resp, c->d_taps, c->d_gauss,    c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur2, c->d_tiles_pyr2, c->d_tiles_pyrblur, c->d_tiles_pyrblur_small,
                   c->d_lcand, c->d_lresp, c->d_lcount};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -982,8 +993,11 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
     std::vector<OrbxTileDesc> t1, t2;
     build_blur_tiles(M, &t1);
     build_frame_tiles(M, ORBX_PYR2_TW, ORBX_PYR2_TH, true, &t2);
-    std::vector<OrbxTileDesc> t3;
-    build_pyrblur_tiles(M, &t3);
+    std::vector<OrbxTileDesc> t3, t4;
+    build_pyrblur_tiles(M, ORBX_PYRBLUR_RH, &t3);
+    build_pyrblur_tiles(M, ORBX_PYRBLUR_RH_SMALL, &t4);
+    c->tiles_small_capacity = t4.size() + 64;
+    CREATE_CHK(hipMalloc((void**)&c->d_tiles_pyrblur_small, c->tiles_small_capacity * sizeof(OrbxTileDesc)));
     c->tiles_frame_capacity = std::max(std::max(t1.size(), t2.size()), t3.size()) + 64;
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_pyrblur, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_blur2, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
@@ -1178,6 +1192,12 @@ int fetch_block(orbx_ctx* c, int b, int first, int n, int32_t* counts, orbx_keyp
   const uint8_t* h = c->h_outb[b];
   if (c->copy_pending[b]) {
     HIPCHK(c, hipEventSynchronize(c->ev_copied[b]));
+  } else if (b == c->blk) {
+    // blocking fetch of the last batch: the copy goes behind the batch on ITS stream (no hop to the copy
+    // stream: the synchronous one-frame call is latency-bound)
+    hipStream_t s = c->last_stream ? c->last_stream : c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->h_outb[b], c->d_outb[b], o.total, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
   } else {
     HIPCHK(c, hipStreamWaitEvent(c->cstream, c->ev_done[b], 0));
     HIPCHK(c, hipMemcpyAsync(c->h_outb[b], c->d_outb[b], o.total, hipMemcpyDeviceToHost, c->cstream));

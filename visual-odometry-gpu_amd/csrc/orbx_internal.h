@@ -114,6 +114,7 @@ constexpr int orbx_fast3_tile_h(int nms_radius) {
 #define ORBX_PYRBLUR_TW 248
 // rows per band of the fused kernel: the y taps of a band's input rows (rows + 6) sit one per lane
 #define ORBX_PYRBLUR_RH 58
+#define ORBX_PYRBLUR_RH_SMALL 12  // few frames per call: many short waves instead
 // pyramid kernel: a wave owns 256 x 8 pixels (level 0 and the levels resized through 8-byte
 // windows) or 256 x 4, a workgroup four times that; OrbxTileDesc::f carries the rows per wave
 #define ORBX_PYR2_TW 256
