@@ -50,23 +50,29 @@ def main():
     it = frames = kps = 0
     while time.time() - t0 < budget:
         w, h = int(rng.integers(24, 420)), int(rng.integers(24, 300))
+        big = rng.random() < 0.04  # now and then a KITTI-sized batch: the tall-band strip table, full FAST grids
+        if big:
+            w, h = int(rng.integers(900, 1300)), int(rng.integers(300, 400))
+        elif rng.random() < 0.15:  # wider than one FAST tile row / several blur strips
+            w = int(rng.integers(420, 900))
         sf = float(rng.choice([1.1, 1.2, 1.2, 1.3, 1.5, 2.0, 2.7]))
         nl = 1
         while nl < 8 and min(w, h) / sf ** nl >= 9 and rng.random() < 0.8:
             nl += 1
         kw = dict(nfeatures=int(rng.choice([0, 1, 7, 100, 500, 2000])), nlevels=nl, scale_factor=sf,
-                  threshold=int(rng.choice([1, 5, 12, 20, 20, 35, 60, 120])), n=int(rng.choice([9, 9, 9, 12, 16, 5, 1])),
+                  threshold=int(rng.choice([0, 1, 5, 12, 20, 20, 35, 60, 120])), n=int(rng.choice([9, 9, 9, 12, 16, 5, 1])),
                   nms_window=int(rng.choice([0, 3, 3, 3, 5, 7])), patch_size=int(rng.choice([31, 31, 9, 15, 1, 41])),
                   harris_window=int(rng.choice([7, 7, 5, 3])), harris_k=float(rng.choice([0.04, 0.06, 0.0])),
                   blur_levels=int(rng.integers(0, 3)), blur_kind=int(rng.integers(0, 2)))
         mode = int(rng.integers(0, 2))
-        B = int(rng.choice([1, 2, 5, 9]))
+        B = 40 if big else int(rng.choice([1, 2, 5, 9]))
         p = pkg.default_params("gpu", max_width=w, max_height=h, max_batch=B, select_mode=mode, **kw)
         imgs = np.stack([image(rng, h, w) for _ in range(B)])
         try:
             with pkg.Context(p) as c:
                 cap = max(c.plan(w, h)["out_capacity"], 1)
                 c.set_fast_early_exit(bool(rng.integers(0, 2)))
+                c.set_fused_pyramid_blur(bool(rng.integers(0, 2)))
                 c.batch_host(imgs)
                 r = c.batch_fetch(0, B, cap)
                 single = c.detect_and_compute(imgs[0])
