@@ -85,7 +85,7 @@ struct orbx_ctx {
   OrbxTileDesc* d_tiles_fast = nullptr;  // one frame, band-major
   size_t tiles_fast_capacity = 0;
   int fast_tiles_count = 0;
-  OrbxTileDesc* d_tiles_blur2 = nullptr;
+  OrbxTileDesc* d_tiles_blur = nullptr;
   OrbxTileDesc* d_tiles_pyr2 = nullptr;
   OrbxTileDesc* d_tiles_pyrblur = nullptr;  // fused pyramid + blur strips
   int pyrblur_tiles_count = 0;
@@ -94,7 +94,7 @@ struct orbx_ctx {
   OrbxTileDesc* d_tiles_pyrblur_small = nullptr;
   int pyrblur_small_count = 0;
   size_t tiles_frame_capacity = 0, tiles_small_capacity = 0;
-  int blur2_tiles_count = 0, pyr2_tiles_count = 0;
+  int blur_tiles_count = 0, pyr2_tiles_count = 0;
   DevBuf s_tiles;  // stage-API tables
   std::vector<OrbxResizeTap> h_taps;
   int plan_w = 0, plan_h = 0;
@@ -567,8 +567,8 @@ int set_plan(orbx_ctx* c, int w, int h) {
     std::vector<OrbxTileDesc> t;
     build_blur_tiles(plan, &t);
     if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "blur tile table exceeds pool");
-    HIPCHK(c, hipMemcpy(c->d_tiles_blur2, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
-    c->blur2_tiles_count = (int)t.size();
+    HIPCHK(c, hipMemcpy(c->d_tiles_blur, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
+    c->blur_tiles_count = (int)t.size();
     build_pyrblur_tiles(plan, ORBX_PYRBLUR_RH, &t);
     if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "strip table exceeds pool");
     HIPCHK(c, hipMemcpy(c->d_tiles_pyrblur, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
@@ -679,7 +679,7 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
     HIPCHK(c, launch_pyramid_auto(c, s, n, d_frames, row_stride, frame_stride));
     HIPCHK(c, mark(1, true));
     if (blur_enabled(c))
-      HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->d_tiles_blur2, c->blur2_tiles_count, n, c->d_pyr,
+      HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->d_tiles_blur, c->blur_tiles_count, n, c->d_pyr,
                                  c->d_pyr_blur, c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
   }
   HIPCHK(c, mark(2, true));
@@ -893,7 +893,7 @@ void orbx_destroy(orbx_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int i = 0; i < orbx_ctx::kGraphs; i++) drop_graph(c, i);
   void* bufs[] = {c->d_in,   c->d_pyr,  c->d_pyr_blur, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total,
-                  c->d_resp, c->d_taps, c->d_gauss,    c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur2, c->d_tiles_pyr2, c->d_tiles_pyrblur, c->d_tiles_pyrblur_small,
+                  c->d_resp, c->d_taps, c->d_gauss,    c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur, c->d_tiles_pyr2, c->d_tiles_pyrblur, c->d_tiles_pyrblur_small,
                   c->d_lcand, c->d_lresp, c->d_lcount};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -1000,7 +1000,7 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_pyrblur_small, c->tiles_small_capacity * sizeof(OrbxTileDesc)));
     c->tiles_frame_capacity = std::max(std::max(t1.size(), t2.size()), t3.size()) + 64;
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_pyrblur, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
-    CREATE_CHK(hipMalloc((void**)&c->d_tiles_blur2, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
+    CREATE_CHK(hipMalloc((void**)&c->d_tiles_blur, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_pyr2, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
   }
   CREATE_CHK(hipMalloc((void**)&c->d_cand, B * (size_t)std::max(M.cand_total, 1) * sizeof(orbx_keypoint)));
@@ -1316,7 +1316,7 @@ int orbx_bench_stage(orbx_ctx* c, int n_frames, int stage, int reps, float* avg_
     switch (stage) {
       case ORBX_STAGE_BLUR:
         if (!blur_enabled(c)) return fail(c, ORBX_ERR_INVALID_ARG, "blur is disabled in this context");
-        HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->d_tiles_blur2, c->blur2_tiles_count, n_frames, c->d_pyr,
+        HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->d_tiles_blur, c->blur_tiles_count, n_frames, c->d_pyr,
                                    c->d_pyr_blur,
                                    c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
         break;
@@ -1619,7 +1619,7 @@ int orbx_build_pyramid_level(orbx_ctx* c, const uint8_t* image, int width, int h
   HIPCHK(c, hipMemcpy2DAsync(c->d_in, width, image, stride, width, height, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, launch_pyramid_auto(c, c->stream, 1, c->d_in, width, (size_t)width * height));
   if (blur_enabled(c))
-    HIPCHK(c, launch_blur_auto(c->stream, P, c->tm_blur, c->d_tiles_blur2, c->blur2_tiles_count, 1, c->d_pyr,
+    HIPCHK(c, launch_blur_auto(c->stream, P, c->tm_blur, c->d_tiles_blur, c->blur_tiles_count, 1, c->d_pyr,
                                c->d_pyr_blur,
                                c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
   const OrbxLevel& L = P.L[level];
