@@ -373,7 +373,11 @@ void build_pyrblur_tiles(const OrbxPlan& plan, int max_rows, std::vector<OrbxTil
   out->clear();
   for (int l = 0; l < plan.nlevels; l++) {
     const OrbxLevel& L = plan.L[l];
-    const int ntx = (L.pitch + ORBX_PYRBLUR_TW - 1) / ORBX_PYRBLUR_TW;  // the padding bytes are (re)written as zeros
+    // dwords that hold image pixels: 62 per strip, one more in the first and in the last strip (their
+    // outer neighbour is a reflection, not another strip's dword).  The padding dwords beyond are not
+    // written by this kernel: they are zeroed when the plan is set.
+    const int dw = (L.w + 3) / 4;
+    const int ntx = dw <= 64 ? 1 : (dw - 2 + 61) / 62;
     const int nb = (L.h + max_rows - 1) / max_rows, rows = (L.h + nb - 1) / nb;
     for (int b = 0; b < nb; b++)
       for (int tx = 0; tx < ntx; tx++) {
@@ -388,6 +392,7 @@ void build_pyrblur_tiles(const OrbxPlan& plan, int max_rows, std::vector<OrbxTil
         d.u0 = L.xtab_off;
         d.u1 = L.ytab_off;
         d.u2 = L.win8;
+        d.pad = (uint32_t)ntx;
         d.img_off = (uint64_t)L.img_off;
         if (d.f > 0) out->push_back(d);
       }
@@ -561,6 +566,12 @@ int set_plan(orbx_ctx* c, int w, int h) {
   HIPCHK(c, hipMemcpy(c->d_taps, c->h_taps.data(), c->h_taps.size() * sizeof(OrbxResizeTap),
                       hipMemcpyHostToDevice));
   c->plan = plan;
+  // the fused pyramid + blur kernel writes only the dwords that hold image pixels; consumers rely on the
+  // padding bytes of a level being zero (BRIEF's zero-extension), and another frame size re-uses the pool
+  if (c->d_pyr_blur) {  // (on the context's stream, and waited for: batches may run on a caller's stream)
+    HIPCHK(c, hipMemsetAsync(c->d_pyr_blur, 0, (size_t)c->p.max_batch * (size_t)c->plan_max.frame_bytes, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   make_tilemap(plan, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &c->tm_blur);
   if ((st = make_bandmap(plan, c->p.nms_window / 2, &c->bm_fast, &why)) != ORBX_OK) return fail(c, st, why);
   {

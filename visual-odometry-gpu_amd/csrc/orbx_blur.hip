@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256) void k_blur3(const OrbxTileDesc* __restrict__ 
 // k_pyramid2, orbx_kernels.hip) -- and feeds it to the streaming blur above.  The un-blurred
 // pyramid is never written nor read back: 2 x 1.5 MB of traffic per frame and one launch less.
 // The halo dwords of a strip have to be COMPUTED here, not loaded, so this kernel keeps the
-// 248-pixel strips (lanes 1..62 productive, lanes 0 / 63 compute the halo and store nothing).
+// 248-pixel strips (lanes 1..62 productive, lanes 0 / 63 compute the halo and store nothing; at the
+// image borders the halo is a reflection and those lanes are productive as well).
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 struct __attribute__((packed, aligned(1))) uint2_unaligned {
@@ -361,7 +362,7 @@ __device__ __forceinline__ void pyrblur_strip(const Blur3Strip& S, const PyrSrc&
   }
 }
 
-// grid = (strip table entries of ONE frame / 4, frames); entry: level `l`, strip `tx` (248 px), rows
+// grid = (strip table entries of ONE frame / 4, frames); entry: level `l`, strip `tx` of `pad` (248 px), rows
 // [ty, ty + f), u0 / u1 / u2 = x-tap offset / y-tap offset / 8-byte-window flag of the level.
 __global__ __launch_bounds__(256, 8) void k_pyrblur(const OrbxTileDesc* __restrict__ tiles, int n_tiles, int frame_bytes,
                                                  int w0, int h0, const uint8_t* __restrict__ in, int in_stride,
@@ -374,7 +375,12 @@ __global__ __launch_bounds__(256, 8) void k_pyrblur(const OrbxTileDesc* __restri
   const int w = d.w, h = d.h, pitch = d.pitch;
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int x = d.tx * ORBX_PYRBLUR_TW - 4 + lane * 4;  // lane 0 holds the dword left of the strip
+  // Strip s starts at dword 62 s: lanes 1..62 are productive, lane 0 / 63 hold the neighbours' dwords --
+  // except at the image borders, where the neighbour is a REFLECTION the lane builds from its own dword:
+  // lane 0 of the first strip and lane 63 of the last one are productive too (a 1241-px level needs
+  // 311 dwords = 63 + 3 x 62 + 63: five strips, not six)
+  const int x = d.tx * ORBX_PYRBLUR_TW + lane * 4;
+  const bool first_strip = d.tx == 0, last_strip = d.tx + 1 == (int)d.pad;
   Blur3Strip S;
   S.y0 = d.ty;
   S.yend = min(d.ty + d.f, h);
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(256, 8) void k_pyrblur(const OrbxTileDesc* __restri
   if (S.y0 >= S.yend) return;
   S.rin = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0, 0x00020000);  // (unused: rows are computed, not loaded)
   S.rout = __builtin_amdgcn_make_buffer_rsrc(dst + ((size_t)f * frame_bytes + d.img_off), 0, pitch * h, 0x00020000);
-  S.voff = (lane >= 1 && lane <= 62 && x < pitch) ? (uint32_t)x : 0xffffffffu;
+  S.voff = ((lane >= 1 || first_strip) && (lane <= 62 || last_strip) && x < pitch) ? (uint32_t)x : 0xffffffffu;
   S.voff_halo = 0xffffffffu;
   // column REFLECT_101 selectors, as in k_blur3
   const int e4 = (w - 1) & ~3, rbyte = (w - 1) & 3;
@@ -395,8 +401,8 @@ __global__ __launch_bounds__(256, 8) void k_pyrblur(const OrbxTileDesc* __restri
   S.selR = edge ? selR_e : 0x03020100u;
   const int nvalid = w - x;
   S.vmask = nvalid >= 4 ? 0xffffffffu : nvalid <= 0 ? 0u : ((1u << (8 * nvalid)) - 1u);
-  const int x_lo = d.tx * ORBX_PYRBLUR_TW - 4, x_hi = x_lo + 4 * 63;
-  const bool patch = (x_lo <= 0) || (e4 >= x_lo && e4 <= x_hi);  // wave-uniform
+  const int x_lo = d.tx * ORBX_PYRBLUR_TW, x_hi = x_lo + 4 * 63;
+  const bool patch = first_strip || (e4 >= x_lo && e4 <= x_hi);  // wave-uniform
 
   PyrSrc P;
   P.src = in + (size_t)f * in_frame_stride;
@@ -460,7 +466,7 @@ hipError_t orbx_launch_blur3(hipStream_t s, const OrbxTileDesc* d_tiles, int n_t
                              const uint8_t* d_src, uint8_t* d_dst, int first_level) {
   if (n_tiles <= 0 || n_frames <= 0) return hipSuccess;
   // four waves per workgroup (measured: 1 -> 53 us, 2 -> 48 us, 4 -> 43 us, 8 / 16 -> 46 us per 64-frame batch)
-  dim3 grid((n_tiles + 3) / 4, n_frames);
+  dim3 grid(((n_tiles + 3) / 4) | 1, n_frames);  // odd: see orbx_launch_pyrblur
   hipLaunchKernelGGL(k_blur3, grid, dim3(256), 0, s, d_tiles, n_tiles, frame_bytes, d_src, d_dst, first_level);
   return hipGetLastError();
 }
@@ -471,7 +477,12 @@ hipError_t orbx_launch_pyrblur(hipStream_t s, const OrbxTileDesc* d_tiles, int n
                                int n_frames, const uint8_t* d_in, int in_stride, size_t in_frame_stride,
                                const OrbxResizeTap* d_taps, uint8_t* d_dst) {
   if (n_tiles <= 0 || n_frames <= 0) return hipSuccess;
-  dim3 grid((n_tiles + 3) / 4, n_frames);
+  // Workgroups are dealt round-robin over the 8 XCDs in linear order (x fastest).  With a grid.x that
+  // shares a factor with 8 every XCD would get the SAME strips of every frame -- one XCD only cheap
+  // level-0 strips, another only resize strips -- and the launch would take as long as the slowest
+  // XCD's share (measured: 32 workgroups per frame 467 us, 35 per frame 345 us).  An odd grid.x rotates
+  // the assignment from frame to frame; the padding workgroup exits at once.
+  dim3 grid(((n_tiles + 3) / 4) | 1, n_frames);
   hipLaunchKernelGGL(k_pyrblur, grid, dim3(256), 0, s, d_tiles, n_tiles, frame_bytes, w0, h0, d_in, in_stride,
                      in_frame_stride, d_taps, d_dst);
   return hipGetLastError();

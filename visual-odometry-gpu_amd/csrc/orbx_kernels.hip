@@ -152,10 +152,11 @@ __device__ __forceinline__ void pyr_rows(const uint8_t* __restrict__ src, int in
   }
 }
 
-__global__ __launch_bounds__(256) void k_pyramid2(const OrbxTileDesc* __restrict__ tiles, int frame_bytes, int w0,
+__global__ __launch_bounds__(256) void k_pyramid2(const OrbxTileDesc* __restrict__ tiles, int n_tiles, int frame_bytes, int w0,
                                                   int h0, const uint8_t* __restrict__ in, int in_stride,
                                                   size_t in_frame_stride, const OrbxResizeTap* __restrict__ taps,
                                                   uint8_t* __restrict__ pyr) {
+  if ((int)blockIdx.x >= n_tiles) return;  // (grid.x is padded to an odd number: orbx_launch_pyramid2)
   const OrbxTileDesc d = tiles[blockIdx.x];  // one scalar load instead of decoding through the plan
   struct {
     int w, h, pitch, xtab_off, ytab_off, win8;
@@ -657,7 +658,11 @@ __global__ __launch_bounds__(LVL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
                                                               int32_t* __restrict__ sel_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ int s_wsum[4][LVL_THREADS / 64];
-  const int l = blockIdx.x, f = blockIdx.y;
+  // grid = (frames, levels), the frame index dispatched fastest.  Workgroups are dealt round-robin over
+  // the 8 XCDs in linear order: with (levels, frames) and 8 levels every XCD got ONE level of every
+  // frame, level 0 (7x the work of level 7) all on one XCD, and the launch took as long as that XCD
+  // needed (84 us per 256 frames; XCD placement is a matter of speed only).
+  const int f = blockIdx.x, l = blockIdx.y;
   const OrbxLevel& L = plan.L[l];
   const int cap = L.cap, cap2 = (cap + 1) & ~1;
   u64* s_key = reinterpret_cast<u64*>(s_dyn);                         // [cap2]
@@ -1618,8 +1623,8 @@ hipError_t orbx_launch_pyramid2(hipStream_t s, const OrbxTileDesc* d_tiles, int 
                                 int h0, int n_frames, const uint8_t* d_in, int in_stride, size_t in_frame_stride,
                                 const OrbxResizeTap* d_taps, uint8_t* d_pyr) {
   if (n_tiles <= 0) return hipSuccess;
-  dim3 grid(n_tiles, n_frames);
-  hipLaunchKernelGGL(k_pyramid2, grid, dim3(256), 0, s, d_tiles, frame_bytes, w0, h0, d_in, in_stride,
+  dim3 grid(n_tiles | 1, n_frames);  // odd: the XCD assignment rotates from frame to frame (orbx_blur.hip)
+  hipLaunchKernelGGL(k_pyramid2, grid, dim3(256), 0, s, d_tiles, n_tiles, frame_bytes, w0, h0, d_in, in_stride,
                      in_frame_stride, d_taps, d_pyr);
   return ORBX_LAUNCH_CHECK();
 }
@@ -1647,7 +1652,7 @@ hipError_t orbx_launch_level_select(hipStream_t s, const OrbxPlan& plan, int n_f
   int maxcap = 2;
   for (int l = 0; l < plan.nlevels; l++) maxcap = plan.L[l].cap > maxcap ? plan.L[l].cap : maxcap;
   const size_t lds = (size_t)((maxcap + 1) & ~1) * 16;
-  dim3 grid(plan.nlevels, n_frames);
+  dim3 grid(n_frames, plan.nlevels);
   hipLaunchKernelGGL(k_level_select, grid, dim3(LVL_THREADS), lds, s, plan, mode, d_mask, d_pyr, d_gauss, window, k,
                      d_sel_lkp, d_sel_resp, d_sel_count);
   return ORBX_LAUNCH_CHECK();
@@ -1685,11 +1690,11 @@ hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frame
   // few keypoints in flight (single frames, small batches): one keypoint per wave, four times the
   // workgroups, a quarter of the serial work per wave; else four per wave
   if ((long long)plan.out_cap * n_frames <= 8192) {
-    dim3 grid((plan.out_cap + 3) / 4, n_frames);
+    dim3 grid(((plan.out_cap + 3) / 4) | 1, n_frames);  // odd: the XCD assignment rotates from frame to frame
     hipLaunchKernelGGL(k_describe2<1>, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
                        d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc);
   } else {
-    dim3 grid((plan.out_cap + 15) / 16, n_frames);
+    dim3 grid(((plan.out_cap + 15) / 16) | 1, n_frames);
     hipLaunchKernelGGL(k_describe2<4>, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
                        d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc);
   }
