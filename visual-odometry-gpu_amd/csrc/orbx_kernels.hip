@@ -1259,7 +1259,9 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
   __shared__ int s_m[DESC_KPB][2];
   __shared__ float s_cs[DESC_KPB][2];
   __shared__ uint2 s_mw[4 * (DESC_PITCH / 4)];
-  const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  // grid = (frames, keypoint groups), the frame index dispatched fastest: with 8 XCDs dealt round-robin all
+  // groups of a frame gather their patches through the same L2 (2.5 % faster than (groups, frames))
+  const int f = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // Final keypoint order = levels back to back (src/orb.cpp:100-102).  The selection
   // kernel left level l's keypoints in static slots; the prefix sums of the per-level
@@ -1268,8 +1270,8 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
   const int lvl_cnt = lane < plan.nlevels ? sel_count[f * plan.nlevels + lane] : 0;
   const int lvl_end = wave_scan_incl(lvl_cnt);  // slots of levels 0..lane
   const int count = __builtin_amdgcn_readlane(lvl_end, 63);
-  if (blockIdx.x == 0 && tid == 0) out_count[f] = count;
-  const int slot0 = blockIdx.x * DESC_KPB;
+  if (grp == 0 && tid == 0) out_count[f] = count;
+  const int slot0 = grp * DESC_KPB;
   if (slot0 >= count) return;  // whole workgroup
   DescLds& lds = s_lds[wave];
   const int pr = patch_size / 2;
@@ -1690,11 +1692,11 @@ hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frame
   // few keypoints in flight (single frames, small batches): one keypoint per wave, four times the
   // workgroups, a quarter of the serial work per wave; else four per wave
   if ((long long)plan.out_cap * n_frames <= 8192) {
-    dim3 grid(((plan.out_cap + 3) / 4) | 1, n_frames);  // odd: the XCD assignment rotates from frame to frame
+    dim3 grid(n_frames, (plan.out_cap + 3) / 4);
     hipLaunchKernelGGL(k_describe2<1>, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
                        d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc);
   } else {
-    dim3 grid(((plan.out_cap + 15) / 16) | 1, n_frames);
+    dim3 grid(n_frames, (plan.out_cap + 15) / 16);
     hipLaunchKernelGGL(k_describe2<4>, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
                        d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc);
   }
