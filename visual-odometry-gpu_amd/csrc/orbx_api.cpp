@@ -369,7 +369,7 @@ void build_blur_tiles(const OrbxPlan& plan, std::vector<OrbxTileDesc>* out) {
 
 // strips of the fused pyramid + blur kernel for ONE frame: 248-px strips (the halo dwords are
 // computed by lanes 0 / 63) x balanced row bands, with the level's resize-table fields
-void build_pyrblur_tiles(const OrbxPlan& plan, int max_rows, std::vector<OrbxTileDesc>* out) {
+void build_pyrblur_tiles(const OrbxPlan& plan, int max_rows, std::vector<OrbxTileDesc>* out, bool heavy_first = false) {
   out->clear();
   for (int l = 0; l < plan.nlevels; l++) {
     const OrbxLevel& L = plan.L[l];
@@ -397,6 +397,21 @@ void build_pyrblur_tiles(const OrbxPlan& plan, int max_rows, std::vector<OrbxTil
         if (d.f > 0) out->push_back(d);
       }
   }
+  if (heavy_first) {
+    // estimated instructions per strip row: level 0 copies, the 8-byte-window levels resize, the others gather
+    auto cost = [](const OrbxTileDesc& d) { return (d.f + 4) * (d.l == 0 ? 35 : d.u2 ? 80 : 90); };
+    std::stable_sort(out->begin(), out->end(),
+                     [&](const OrbxTileDesc& a, const OrbxTileDesc& b) { return cost(a) > cost(b); });
+  }
+}
+
+// ORBX_PYR_GROUP=g: frames per dispatch group of the fused pyramid + blur kernel (0: frame-major grid)
+int pyr_group_env() {
+  static const int v = [] {
+    const char* e = getenv("ORBX_PYR_GROUP");
+    return e ? atoi(e) : 32;
+  }();
+  return v;
 }
 
 int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string* why) {
@@ -580,7 +595,7 @@ int set_plan(orbx_ctx* c, int w, int h) {
     if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "blur tile table exceeds pool");
     HIPCHK(c, hipMemcpy(c->d_tiles_blur, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
     c->blur_tiles_count = (int)t.size();
-    build_pyrblur_tiles(plan, ORBX_PYRBLUR_RH, &t);
+    build_pyrblur_tiles(plan, ORBX_PYRBLUR_RH, &t, pyr_group_env() > 0);
     if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "strip table exceeds pool");
     HIPCHK(c, hipMemcpy(c->d_tiles_pyrblur, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
     c->pyrblur_tiles_count = (int)t.size();
@@ -685,7 +700,8 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
     const bool small = (long long)n * c->pyrblur_tiles_count < 4096;
     HIPCHK(c, orbx_launch_pyrblur(s, small ? c->d_tiles_pyrblur_small : c->d_tiles_pyrblur,
                                   small ? c->pyrblur_small_count : c->pyrblur_tiles_count, P.frame_bytes, P.w0, P.h0, n,
-                                  d_frames, row_stride, frame_stride, c->d_taps, c->d_pyr_blur));
+                                  d_frames, row_stride, frame_stride, c->d_taps, c->d_pyr_blur,
+                                  small ? 0 : pyr_group_env()));
   } else {
     HIPCHK(c, launch_pyramid_auto(c, s, n, d_frames, row_stride, frame_stride));
     HIPCHK(c, mark(1, true));

@@ -367,13 +367,23 @@ __device__ __forceinline__ void pyrblur_strip(const Blur3Strip& S, const PyrSrc&
 __global__ __launch_bounds__(256, 8) void k_pyrblur(const OrbxTileDesc* __restrict__ tiles, int n_tiles, int frame_bytes,
                                                  int w0, int h0, const uint8_t* __restrict__ in, int in_stride,
                                                  size_t in_frame_stride, const OrbxResizeTap* __restrict__ taps,
-                                                 uint8_t* __restrict__ dst) {
+                                                 uint8_t* __restrict__ dst, int group, int n_frames) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ti = blockIdx.x * 4 + wave;
+  int wg = blockIdx.x, f = blockIdx.y;
+  if (group) {
+    // 1-D grid: groups of `group` frames one after the other; inside a group the workgroup index of the
+    // (cost-sorted, heaviest first) strip table is the slow index and the frame the fast one
+    const int nwg = (n_tiles + 3) >> 2, per_group = group * nwg;
+    const int g = blockIdx.x / per_group, r = blockIdx.x - g * per_group;
+    const int gsize = min(group, n_frames - g * group);
+    wg = r / gsize;
+    f = g * group + (r - wg * gsize);
+    if (wg >= nwg) return;  // (the last, smaller group)
+  }
+  const int ti = wg * 4 + wave;
   if (ti >= n_tiles) return;  // whole wave
   const OrbxTileDesc d = tiles[ti];
   const int w = d.w, h = d.h, pitch = d.pitch;
-  const int f = blockIdx.y;
   const int lane = threadIdx.x & 63;
   // Strip s starts at dword 62 s: lanes 1..62 are productive, lane 0 / 63 hold the neighbours' dwords --
   // except at the image borders, where the neighbour is a REFLECTION the lane builds from its own dword:
@@ -475,8 +485,14 @@ hipError_t orbx_launch_blur3(hipStream_t s, const OrbxTileDesc* d_tiles, int n_t
 // table of ONE frame (orbx_api.cpp: build_pyrblur_tiles)
 hipError_t orbx_launch_pyrblur(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int w0, int h0,
                                int n_frames, const uint8_t* d_in, int in_stride, size_t in_frame_stride,
-                               const OrbxResizeTap* d_taps, uint8_t* d_dst) {
+                               const OrbxResizeTap* d_taps, uint8_t* d_dst, int group) {
   if (n_tiles <= 0 || n_frames <= 0) return hipSuccess;
+  if (group > 0) {
+    const int nwg = (n_tiles + 3) / 4, ngroups = (n_frames + group - 1) / group;
+    hipLaunchKernelGGL(k_pyrblur, dim3((unsigned)(ngroups * group * nwg)), dim3(256), 0, s, d_tiles, n_tiles, frame_bytes,
+                       w0, h0, d_in, in_stride, in_frame_stride, d_taps, d_dst, group, n_frames);
+    return hipGetLastError();
+  }
   // Workgroups are dealt round-robin over the 8 XCDs in linear order (x fastest).  With a grid.x that
   // shares a factor with 8 every XCD would get the SAME strips of every frame -- one XCD only cheap
   // level-0 strips, another only resize strips -- and the launch would take as long as the slowest
@@ -484,6 +500,6 @@ hipError_t orbx_launch_pyrblur(hipStream_t s, const OrbxTileDesc* d_tiles, int n
   // the assignment from frame to frame; the padding workgroup exits at once.
   dim3 grid(((n_tiles + 3) / 4) | 1, n_frames);
   hipLaunchKernelGGL(k_pyrblur, grid, dim3(256), 0, s, d_tiles, n_tiles, frame_bytes, w0, h0, d_in, in_stride,
-                     in_frame_stride, d_taps, d_dst);
+                     in_frame_stride, d_taps, d_dst, 0, n_frames);
   return hipGetLastError();
 }

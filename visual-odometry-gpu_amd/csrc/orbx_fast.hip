@@ -270,11 +270,10 @@ __global__ __launch_bounds__(256) void k_fast3(const OrbxTileDesc* __restrict__ 
   __shared__ __attribute__((aligned(16))) uint32_t s_img32[G::IMG_ROWS * G::IMG_DW];
   __shared__ __attribute__((aligned(16))) uint16_t s_score[(G::SC_ROWS + 2 * R) * G::SC_PITCH + 16];
   __shared__ uint16_t s_queue[G::QCAP];
-  __shared__ __attribute__((aligned(8))) uint32_t s_mask32[G::TH * G::MASK_DW];
+  __shared__ __attribute__((aligned(16))) uint32_t s_mask32[G::TH * G::MASK_DW];
   __shared__ int s_qn;
   __shared__ int s_wtot[4];
   __shared__ int s_skip;
-  __shared__ int s_surv;
   // NMS reads (2R+1)^2 neighbourhoods of score rows 0 .. SC_ROWS-1: R guard rows above and below
   uint16_t* const score0 = s_score + R * G::SC_PITCH + 8;
 
@@ -283,7 +282,7 @@ __global__ __launch_bounds__(256) void k_fast3(const OrbxTileDesc* __restrict__ 
   // before tile row b+1 of any frame, and the table is shared by all frames (scalar cache).
   const int f = blockIdx.x;
   const OrbxTileDesc d = tiles[blockIdx.y];
-  const int w = d.w, h = d.h, pitch = d.pitch, cap = d.u0, mask_wpr = d.u1, tiles_x = d.u2;
+  const int w = d.w, h = d.h, pitch = d.pitch, cap = d.u0, tiles_x = d.u2;
   const int tx = d.tx, ty = d.ty;
   // tile height of this level (<= G::TH; the host balances the tile rows of a level) and the rows
   // each walking thread then owns (K, or K-1 for the shorter tiles)
@@ -293,7 +292,6 @@ __global__ __launch_bounds__(256) void k_fast3(const OrbxTileDesc* __restrict__ 
   const int tid = threadIdx.x;
   const int thr = fp.threshold;
   const int x0 = tx * G::TW, y0 = ty * th;
-  u64* mrow = mask + ((size_t)f * (size_t)mask_words + d.mask_off);
   // per frame: ORBX_MAX_LEVELS x ORBX_MAX_BANDS tile-row statistics, then one "dead from tile row"
   // word per level
   u64* fstat = row_stat ? row_stat + (size_t)f * ORBX_FAST_STAT_WORDS : nullptr;
@@ -329,38 +327,35 @@ __global__ __launch_bounds__(256) void k_fast3(const OrbxTileDesc* __restrict__ 
     if (s_skip) return;
   }
 
-  // ---- phase 1: tile + halo -> LDS (8-byte loads; x0-8 is 8-byte aligned, pitch a multiple of 64)
+  // ---- phase 1: tile + halo -> LDS (8-byte loads; x0-8 is 8-byte aligned, pitch a multiple of 64).
+  // Only pixels whose whole ring lies inside the image can become candidates (the flags of all others
+  // are masked below), so what the tile holds OUTSIDE the image is never looked at: the addresses
+  // are clamped into the level instead of predicating every load (and LDS rows past the tile's own
+  // img_rows are simply loaded too: the LDS tile always has G::IMG_ROWS rows).
   {
     constexpr int CPR = G::IMG_PITCH / 8;  // 18 loads per row
     constexpr int RPP = 256 / CPR;         // 14 rows per pass
     constexpr int NP = (G::IMG_ROWS + RPP - 1) / RPP;
-    const int img_rows = th + 2 * R + 6;   // <= G::IMG_ROWS
     const int r0 = (tid * 3641) >> 16;     // tid / 18
     const int c = tid - r0 * CPR;
-    const int gx = x0 - 8 + 8 * c;
-    const bool xok = (unsigned)gx < (unsigned)pitch && r0 < RPP;
+    const int gx = min(max(x0 - 8 + 8 * c, 0), pitch - 8);
     const int gy0 = y0 - R - 3 + r0;
     uint2 v[NP];
 #pragma unroll
     for (int k = 0; k < NP; k++) {
-      const int gy = gy0 + RPP * k;
-      v[k] = make_uint2(0u, 0u);
-      if (xok && (unsigned)gy < (unsigned)h && r0 + RPP * k < img_rows)
-        v[k] = *reinterpret_cast<const uint2*>(img + (uint32_t)(gy * pitch + gx));
+      const int gy = min(max(gy0 + RPP * k, 0), h - 1);
+      v[k] = *reinterpret_cast<const uint2*>(img + (uint32_t)(gy * pitch + gx));
     }
     // zero the score tile (and its guard rows) and the survivor mask while the loads are in flight
     {
       constexpr int NZ = (int)(sizeof(s_score) / 16);
       for (int i = tid; i < NZ; i += 256) reinterpret_cast<uint4*>(s_score)[i] = make_uint4(0u, 0u, 0u, 0u);
       for (int i = tid; i < G::TH * G::MASK_DW; i += 256) s_mask32[i] = 0u;
-      if (tid == 0) {
-        s_qn = 0;
-        s_surv = 0;
-      }
+      if (tid == 0) s_qn = 0;
     }
 #pragma unroll
     for (int k = 0; k < NP; k++)
-      if (r0 < RPP && r0 + RPP * k < img_rows)
+      if (r0 + RPP * k < G::IMG_ROWS)  // (threads 252..255 have r0 == 14: rows 14, 28, 42, 56 twice -- same data)
         reinterpret_cast<uint2*>(s_img32)[(r0 + RPP * k) * CPR + c] = v[k];
   }
   __syncthreads();
@@ -465,37 +460,43 @@ __global__ __launch_bounds__(256) void k_fast3(const OrbxTileDesc* __restrict__ 
   }
   __syncthreads();
 
-  // ---- phase 5: one 8-byte store per mask word of the tile; the tile's survivor count joins the
-  // tile-row statistics
-  {
-    constexpr int WPR = G::TW / 64;  // mask words per tile row
+  // ---- phase 5 (first wave only): lane = tile row, its two mask words leave with one 16-byte store;
+  // the tile's survivor count joins the tile-row statistics.  The tile record is loaded AGAIN (one
+  // scalar load through a pointer the optimiser cannot see through): keeping its fields alive across
+  // the arc test, which wants every SGPR, cost ~50 v_writelane / v_readlane spill instructions per wave.
+  const OrbxTileDesc* tp = tiles + blockIdx.y;
+  asm volatile("" : "+s"(tp));
+  const OrbxTileDesc e = *tp;
+  const int th5 = e.f, y05 = e.ty * th5, h5 = e.h;
+  if (tid < 64) {
+    static_assert(G::TH <= 64 && G::MASK_DW == 4, "one lane per tile row, two 64-bit words per row");
     int surv = 0;
-    if (tid < th * WPR) {
-      const int iy = tid / WPR, wj = tid - iy * WPR;
-      const int gy = y0 + iy, gw = tx * WPR + wj;
-      const u64 word = reinterpret_cast<const u64*>(s_mask32)[tid];
-      if (gy < h && gw < mask_wpr) {
-        mrow[(size_t)gy * mask_wpr + gw] = word;
-        surv = __popcll(word);
+    const int gy = y05 + tid, gw = e.tx * 2, wpr = e.u1;
+    if (tid < th5 && gy < h5) {
+      const uint4 m = reinterpret_cast<const uint4*>(s_mask32)[tid];
+      u64* dst = mask + ((size_t)blockIdx.x * (size_t)mask_words + e.mask_off) + ((size_t)gy * wpr + gw);
+      if (gw + 1 < wpr) {
+        typedef uint32_t __attribute__((ext_vector_type(4), aligned(8))) u32x4_a8;
+        *reinterpret_cast<u32x4_a8*>(dst) = u32x4_a8{m.x, m.y, m.z, m.w};
+        surv = __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w);
+      } else {  // the level's last mask word is the tile's first
+        *dst = (u64)m.x | ((u64)m.y << 32);
+        surv = __popc(m.x) + __popc(m.y);
       }
     }
-    if (stat) {
-      static_assert(G::TH * WPR <= 128, "survivor count: two waves");
-      if (tid < 128) {
-        const int ws = wave_sum(surv);
-        if ((tid & 63) == 0) atomicAdd(&s_surv, ws);
-      }
-      __syncthreads();
+    if (row_stat) {
+      const int ws = wave_sum(surv);
       if (tid == 0)
-        __hip_atomic_fetch_add(&stat[ty], (1ull << 32) | (u64)(uint32_t)s_surv, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(row_stat + (size_t)blockIdx.x * ORBX_FAST_STAT_WORDS + e.stat_index + e.ty,
+                               (1ull << 32) | (u64)(uint32_t)ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (scores_out) {  // stage operator Fast()/orbx_fast_score: the dense score map
-    for (int i = tid; i < th * G::TW; i += 256) {
+    const int w5 = e.w, x05 = e.tx * G::TW;
+    for (int i = tid; i < th5 * G::TW; i += 256) {
       const int iy = i / G::TW, ix = i - iy * G::TW;
-      const int gy = y0 + iy, gx = x0 + ix;
-      if (gy < h && gx < w) scores_out[(size_t)gy * w + gx] = score0[(iy + R) * G::SC_PITCH + ix + 4];
+      const int gy = y05 + iy, gx = x05 + ix;
+      if (gy < h5 && gx < w5) scores_out[(size_t)gy * w5 + gx] = score0[(iy + R) * G::SC_PITCH + ix + 4];
     }
   }
 }

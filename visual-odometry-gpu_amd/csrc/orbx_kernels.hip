@@ -1242,8 +1242,8 @@ __device__ __forceinline__ f2_t lround_f2(f2_t v) {
   return t + __builtin_elementwise_trunc(fr + fr);
 }
 
-template <int DESC_KPW>
-__global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t* __restrict__ pyr, int patch_size,
+template <int DESC_KPW, int DESC_NW>
+__global__ __launch_bounds__(64 * DESC_NW) void k_describe2(OrbxPlan plan, const uint8_t* __restrict__ pyr, int patch_size,
                                                    const int32_t* __restrict__ sel_count,
                                                    const orbx_keypoint* __restrict__ sel_lkp,
                                                    const float* __restrict__ sel_resp,
@@ -1254,8 +1254,9 @@ __global__ __launch_bounds__(256) void k_describe2(OrbxPlan plan, const uint8_t*
                                                    orbx_keypoint* __restrict__ out_kp,
                                                    float* __restrict__ out_angle,
                                                    orbx_descriptor* __restrict__ out_desc) {
-  constexpr int DESC_KPB = 4 * DESC_KPW;
-  __shared__ __attribute__((aligned(16))) DescLds s_lds[4];
+  constexpr int DESC_KPB = DESC_NW * DESC_KPW;
+  static_assert(2 * DESC_KPB <= 64 * DESC_NW, "trig: two threads per keypoint");
+  __shared__ __attribute__((aligned(16))) DescLds s_lds[DESC_NW];
   __shared__ int s_m[DESC_KPB][2];
   __shared__ float s_cs[DESC_KPB][2];
   __shared__ uint2 s_mw[4 * (DESC_PITCH / 4)];
@@ -1693,11 +1694,12 @@ hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frame
   // workgroups, a quarter of the serial work per wave; else four per wave
   if ((long long)plan.out_cap * n_frames <= 8192) {
     dim3 grid(n_frames, (plan.out_cap + 3) / 4);
-    hipLaunchKernelGGL(k_describe2<1>, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
+    hipLaunchKernelGGL((k_describe2<1, 4>), grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
                        d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc);
   } else {
-    dim3 grid(n_frames, (plan.out_cap + 15) / 16);
-    hipLaunchKernelGGL(k_describe2<4>, grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
+    // eight waves of four keypoints: the 64 trig threads (two per keypoint) fill one wave
+    dim3 grid(n_frames, (plan.out_cap + 31) / 32);
+    hipLaunchKernelGGL((k_describe2<4, 8>), grid, dim3(512), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
                        d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc);
   }
   return ORBX_LAUNCH_CHECK();
