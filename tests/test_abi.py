@@ -110,5 +110,7 @@ def test_no_result_altering_environment_switch_in_the_shipping_library():
         "ORBX_SELECT_SPREAD",  # fused vs three-kernel selection
         "ORBX_BLUR_IMPL",      # first- vs second-generation separable blur kernel
         "ORBX_FUSE",           # 0: pyramid and blur as two kernels instead of one
+        "ORBX_PYR_GROUP",      # frames per dispatch group of the fused kernel (tests/test_batch64_parity.py)
+        "ORBX_FAST_CHUNK",     # tiles per FAST workgroup (tests/test_batch64_parity.py)
     }
     assert found <= allowed, sorted(found - allowed)

@@ -90,3 +90,47 @@ def test_full_work_equals_early_exit_at_batch_64(pkg, frames, oracle_results):
         compare(res, oracle_results, cap)
         worked, total = c.fast_tile_counts()
         assert worked == total
+
+
+_SWITCH_PROBE = r"""
+import importlib, sys
+import torch
+sys.path.insert(0, %r)
+bench = importlib.import_module("bench")
+pkg = importlib.import_module("visual-odometry-gpu_amd")
+PK = %r
+B, W, H = 64, 1241, 376
+frames = bench.stream_a(B)
+p = pkg.default_params("gpu", max_width=W, max_height=H, max_batch=B, **PK)
+with pkg.Context(p) as c:
+    cap = c.plan(W, H)["out_capacity"]
+    d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    c.batch_device(d.data_ptr(), B, W, H)
+    res = c.batch_fetch(0, B, cap)
+    print("CHECKSUM", int(res["counts"].sum()), pkg.shard.descriptor_checksum(res["counts"], res["desc"]))
+"""
+
+
+@pytest.mark.parametrize("env", [{"ORBX_PYR_GROUP": "0", "ORBX_FAST_CHUNK": "1"},
+                                 {"ORBX_PYR_GROUP": "7", "ORBX_FAST_CHUNK": "5"},
+                                 {"ORBX_PYR_GROUP": "256", "ORBX_FAST_CHUNK": "64"}])
+def test_dispatch_shape_switches_do_not_change_results(pkg, oracle_results, env):
+    """ORBX_PYR_GROUP (frames per dispatch group of the fused pyramid + blur kernel) and ORBX_FAST_CHUNK
+    (tiles per FAST workgroup) are read once per process: a child process per setting, same checksum
+    as the oracle's (tests/test_abi.py lists them as result-preserving switches)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", _SWITCH_PROBE % (root, PK)], env=e, capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("CHECKSUM")][-1].split()
+    shard = pkg.shard
+    want = shard.descriptor_checksum([len(r["kps"]) for r in oracle_results], [r["desc"] for r in oracle_results])
+    assert int(line[1]) == sum(len(r["kps"]) for r in oracle_results)
+    assert int(line[2]) == want
