@@ -320,6 +320,7 @@ def main():
     dt = grp.max_float(dt)
     nframes_all = grp.sum_int(nframes)
     fast_tiles = ctx.fast_tile_counts()  # (did the full work, all) of the last timed step
+    pyr_done = ctx.pyramid_pixel_counts()  # (pyramid pixels produced, all) of the last timed step
     nread = min(steps, 64)
     roof_ms = {"blur": 0.0, "fast_nms": 0.0}
     for back in range(nread):
@@ -495,17 +496,30 @@ def main():
             return e
 
         work_frac = fast_tiles[0] / max(fast_tiles[1], 1)
+        pyr_frac = pyr_done[0] / max(pyr_done[1], 1)
         fused = not args.unfused
         kern = {}
         if fused:
             # the timed region builds and blurs the pyramid in ONE kernel.  Charged with the stage figures of
             # SURVEY.md §8d (resize + blur); `bytes_moved` = what the fused kernel has to move at all (level 0
-            # read once + every blurred level written once)
+            # read once + every blurred level written once).  With the early exit on the pyramid is built top
+            # rows first and rows nobody reads are not produced: the timed-region entry charges only the
+            # produced pixels; the every-row figure comes from the pass with the early exit off.
             moved = (W * H + pyr_px) * B
+            charged = (W * H + (pyr_px - W * H)) * B + alg["blur"]
+            if full_ms.get("blur", 0) > 0 and not args.only_timed:
+                kern["pyramid_blur_fused_every_row"] = entry(
+                    "pyrblur", charged, full_ms["blur"], "k_pyrblur_every_row",
+                    {"compulsory_bytes_of_the_fused_kernel": moved, "achieved_GBps_compulsory": gbs(moved, full_ms["blur"]),
+                     "note": "early exit off: one launch, every pyramid row produced; charged with SURVEY.md §8d's "
+                             "resize + blur figures; the un-blurred pyramid is never written"})
             kern["pyramid_blur_fused_timed_region"] = entry(
-                "pyrblur", (W * H + (pyr_px - W * H)) * B + alg["blur"], roof_ms["blur"], "k_pyrblur",
-                {"compulsory_bytes_of_the_fused_kernel": moved, "achieved_GBps_compulsory": gbs(moved, roof_ms["blur"]),
-                 "note": "charged with SURVEY.md §8d's resize + blur figures; the un-blurred pyramid is never written"})
+                "pyrblur", charged * pyr_frac, roof_ms["blur"], "k_pyrblur",
+                {"compulsory_bytes_of_the_fused_kernel": moved * pyr_frac,
+                 "achieved_GBps_compulsory": gbs(moved * pyr_frac, roof_ms["blur"]),
+                 "pyramid_pixels_produced": pyr_done[0], "pyramid_pixels": pyr_done[1],
+                 "note": "production: top rows first (two launches, their time summed); bytes charged = produced "
+                         "pixels / all pixels x (resize + blur figures of SURVEY.md §8d)"})
         src_ms = unfused_ms if fused else stage_ms
         if src_ms:
             kern["pyramid_alone"] = entry("pyramid", alg["pyramid"], src_ms["pyramid"], "k_pyramid2")
@@ -539,7 +553,8 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl, "frames_per_step_per_gpu": B, "distinct_resident_batches": len(batches),
                        "sharding": "frame-parallel, no data-path collective",
-                       "fast_early_exit": not args.full_work, "pyramid_blur_fused": not args.unfused},
+                       "fast_early_exit": not args.full_work, "pyramid_blur_fused": not args.unfused,
+                       "pyramid_top_rows_first": bool(pyr_done[0] < pyr_done[1])},
             "roofline": {"bound": "hbm", "kernel": "k_blur3 (stand-alone)" if dom == "blur_alone" else "k_fast3 (every tile working)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": kern.get(dom, {}).get("hbm_traffic_bytes_per_launch"),
@@ -554,6 +569,7 @@ def main():
                          "pmc_counters": "profiles/r02/pmc_counters.json (same kernel sources)" if pmc else None},
             "roofline_kernels_ms": roof_ms,
             "fast_tiles": {"full_work": fast_tiles[0], "total": fast_tiles[1], "early_exit_frac": 1.0 - work_frac},
+            "pyramid_pixels": {"produced": pyr_done[0], "total": pyr_done[1], "produced_frac": pyr_frac},
             "stage_ms_per_step": stage_ms,
             "stage_ms_per_step_fast_full_work": full_ms,
             "stage_ms_per_step_unfused": unfused_ms,

@@ -202,6 +202,13 @@ int orbx_set_fused_pyramid_blur(orbx_ctx* ctx, int enable);
  * exit.  With the early exit disabled worked == total. */
 int orbx_fast_tile_counts(orbx_ctx* ctx, long long* worked, long long* total);
 
+/* Same for the pyramid: pyramid pixels the last whole-path batch PRODUCED out of all pyramid pixels of its
+ * frames.  With blur on every level, the FAST early exit on and a large batch, the pyramid is built top rows
+ * first and the remaining rows of a level are produced only if its top FAST tile rows did not already hold
+ * the level's `cap` survivors (they are never read otherwise; results are identical).  Otherwise
+ * produced == total. */
+int orbx_pyramid_pixel_counts(orbx_ctx* ctx, long long* produced, long long* total);
+
 /* Runs only the blur + FAST/NMS stages of the last-built pyramid `reps` times
  * (the roofline kernels) and reports the average duration of
  * each, measured with HIP events on the context's stream. */

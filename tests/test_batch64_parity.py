@@ -112,12 +112,13 @@ with pkg.Context(p) as c:
 """
 
 
-@pytest.mark.parametrize("env", [{"ORBX_PYR_GROUP": "0", "ORBX_FAST_CHUNK": "1"},
-                                 {"ORBX_PYR_GROUP": "7", "ORBX_FAST_CHUNK": "5"},
-                                 {"ORBX_PYR_GROUP": "256", "ORBX_FAST_CHUNK": "64"}])
+@pytest.mark.parametrize("env", [{"ORBX_PYR_GROUP": "0", "ORBX_FAST_CHUNK": "1", "ORBX_TOP_ROWS": "0"},
+                                 {"ORBX_PYR_GROUP": "7", "ORBX_FAST_CHUNK": "5", "ORBX_TOP_ROWS": "1"},
+                                 {"ORBX_PYR_GROUP": "256", "ORBX_FAST_CHUNK": "64", "ORBX_TOP_ROWS": "3"}])
 def test_dispatch_shape_switches_do_not_change_results(pkg, oracle_results, env):
-    """ORBX_PYR_GROUP (frames per dispatch group of the fused pyramid + blur kernel) and ORBX_FAST_CHUNK
-    (tiles per FAST workgroup) are read once per process: a child process per setting, same checksum
+    """ORBX_PYR_GROUP (frames per dispatch group of the fused pyramid + blur kernel), ORBX_FAST_CHUNK
+    (tiles per FAST workgroup) and ORBX_TOP_ROWS (tile rows of the first pass of the top-rows-first
+    pipeline) are read once per process: a child process per setting, same checksum
     as the oracle's (tests/test_abi.py lists them as result-preserving switches)."""
     import os
     import subprocess

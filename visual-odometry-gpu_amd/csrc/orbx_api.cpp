@@ -93,6 +93,10 @@ struct orbx_ctx {
   // fill the chip only with many short waves, where a large batch wants few tall ones
   OrbxTileDesc* d_tiles_pyrblur_small = nullptr;
   int pyrblur_small_count = 0;
+  // top-rows-first pipeline: the strips of the first pass and of the second one
+  OrbxTileDesc* d_tiles_pyrblur_top = nullptr;
+  OrbxTileDesc* d_tiles_pyrblur_rest = nullptr;
+  int pyrblur_top_count = 0, pyrblur_rest_count = 0;
   size_t tiles_frame_capacity = 0, tiles_small_capacity = 0;
   int blur_tiles_count = 0, pyr2_tiles_count = 0;
   DevBuf s_tiles;  // stage-API tables
@@ -138,6 +142,7 @@ struct orbx_ctx {
   OutLayout out_layout{};
   int out_cap = 0;  // slot capacity of the pool (plan_max.out_cap)
   int last_n = 0;
+  bool last_two_pass = false;  // the last batch built its pyramid top rows first (enqueue_batch)
   hipStream_t last_stream = nullptr;
 
   // stage-API scratch (grown on demand; never touched by the batched path)
@@ -156,8 +161,10 @@ struct orbx_ctx {
   int fuse = 1;  // pyramid + blur in one kernel when blur runs on every level (orbx_set_fused_pyramid_blur)
   // ring of event sets: one per timed batched call, so that several calls can be
   // in flight before their stage times are read (no host sync between steps)
-  hipEvent_t evr[ORBX_EVENT_SETS][ORBX_NUM_STAGE_TIMES + 1] = {};
+  // (slots ORBX_NUM_STAGE_TIMES + 1, + 2: the boundaries inside the top-rows-first pipeline)
+  hipEvent_t evr[ORBX_EVENT_SETS][ORBX_NUM_STAGE_TIMES + 3] = {};
   int ev_mode[ORBX_EVENT_SETS] = {};
+  bool ev_split[ORBX_EVENT_SETS] = {};
   long long ev_calls = 0;  // timed batched calls so far
   hipEvent_t ev[2] = {};   // orbx_bench_stage
 };
@@ -368,8 +375,18 @@ void build_blur_tiles(const OrbxPlan& plan, std::vector<OrbxTileDesc>* out) {
 }
 
 // strips of the fused pyramid + blur kernel for ONE frame: 248-px strips (the halo dwords are
-// computed by lanes 0 / 63) x balanced row bands, with the level's resize-table fields
-void build_pyrblur_tiles(const OrbxPlan& plan, int max_rows, std::vector<OrbxTileDesc>* out, bool heavy_first = false) {
+// computed by lanes 0 / 63) x balanced row bands, with the level's resize-table fields.
+// part 0: every row.  Top-rows-first pipeline (enqueue_batch): part 1 = the rows the FAST tiles of the
+// first `top_rows` tile rows and the descriptors of their keypoints can read -- rows below
+// top_rows * tile_h + ORBX_TOP_MARGIN -- and part 2 = the rest, whose strips carry what the kernel's skip
+// test needs (stat_index, mask_off = tile rows of the first pass << 32 | cap).
+#define ORBX_TOP_MARGIN 21  // a descriptor reaches DESC_R = 20 rows below its keypoint (orbx_kernels.hip); Harris, FAST less
+int pyrblur_first_pass_rows(const OrbxPlan& plan, const OrbxBandMap& bm, int l, int top_rows) {
+  if (top_rows <= 0 || bm.tiles_y[l] <= top_rows) return plan.L[l].h;
+  return std::min(plan.L[l].h, top_rows * bm.tile_h[l] + ORBX_TOP_MARGIN);
+}
+void build_pyrblur_tiles(const OrbxPlan& plan, int max_rows, std::vector<OrbxTileDesc>* out, bool heavy_first = false,
+                         int part = 0, const OrbxBandMap* bm = nullptr, int top_rows = 0) {
   out->clear();
   for (int l = 0; l < plan.nlevels; l++) {
     const OrbxLevel& L = plan.L[l];
@@ -378,14 +395,17 @@ void build_pyrblur_tiles(const OrbxPlan& plan, int max_rows, std::vector<OrbxTil
     // written by this kernel: they are zeroed when the plan is set.
     const int dw = (L.w + 3) / 4;
     const int ntx = dw <= 64 ? 1 : (dw - 2 + 61) / 62;
-    const int nb = (L.h + max_rows - 1) / max_rows, rows = (L.h + nb - 1) / nb;
+    const int split = part == 0 ? L.h : pyrblur_first_pass_rows(plan, *bm, l, top_rows);
+    const int r0 = part == 2 ? split : 0, r1 = part == 1 ? split : L.h;
+    if (r1 <= r0) continue;
+    const int nb = (r1 - r0 + max_rows - 1) / max_rows, rows = (r1 - r0 + nb - 1) / nb;
     for (int b = 0; b < nb; b++)
       for (int tx = 0; tx < ntx; tx++) {
         OrbxTileDesc d{};
         d.l = l;
         d.tx = tx;
-        d.ty = b * rows;
-        d.f = std::min(rows, L.h - b * rows);
+        d.ty = r0 + b * rows;
+        d.f = std::min(rows, r1 - d.ty);
         d.w = L.w;
         d.h = L.h;
         d.pitch = L.pitch;
@@ -394,6 +414,10 @@ void build_pyrblur_tiles(const OrbxPlan& plan, int max_rows, std::vector<OrbxTil
         d.u2 = L.win8;
         d.pad = (uint32_t)ntx;
         d.img_off = (uint64_t)L.img_off;
+        if (part == 2) {
+          d.stat_index = (uint32_t)(l * ORBX_MAX_BANDS);
+          d.mask_off = ((uint64_t)(uint32_t)std::min(top_rows, bm->tiles_y[l]) << 32) | (uint32_t)L.cap;
+        }
         if (d.f > 0) out->push_back(d);
       }
   }
@@ -412,6 +436,15 @@ int pyr_group_env() {
     return e ? atoi(e) : 32;
   }();
   return v;
+}
+
+// ORBX_TOP_ROWS=k: FAST tile rows of the first pass of the top-rows-first pipeline (0: one pass)
+int top_rows_env() {
+  static const int v = [] {
+    const char* e = getenv("ORBX_TOP_ROWS");
+    return e ? atoi(e) : 2;
+  }();
+  return v < 0 ? 0 : v;
 }
 
 int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string* why) {
@@ -599,6 +632,15 @@ int set_plan(orbx_ctx* c, int w, int h) {
     if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "strip table exceeds pool");
     HIPCHK(c, hipMemcpy(c->d_tiles_pyrblur, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
     c->pyrblur_tiles_count = (int)t.size();
+    build_pyrblur_tiles(plan, ORBX_PYRBLUR_RH, &t, pyr_group_env() > 0, 1, &c->bm_fast, top_rows_env());
+    if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "strip table exceeds pool");
+    HIPCHK(c, hipMemcpy(c->d_tiles_pyrblur_top, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
+    c->pyrblur_top_count = (int)t.size();
+    build_pyrblur_tiles(plan, ORBX_PYRBLUR_RH, &t, pyr_group_env() > 0, 2, &c->bm_fast, top_rows_env());
+    if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "strip table exceeds pool");
+    if (!t.empty())
+      HIPCHK(c, hipMemcpy(c->d_tiles_pyrblur_rest, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
+    c->pyrblur_rest_count = (int)t.size();
     build_pyrblur_tiles(plan, ORBX_PYRBLUR_RH_SMALL, &t);
     if (t.size() > c->tiles_small_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "strip table exceeds pool");
     HIPCHK(c, hipMemcpy(c->d_tiles_pyrblur_small, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
@@ -692,16 +734,46 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
   // around the FAST stage bracket the kernel alone
   HIPCHK(c, hipMemsetAsync(c->d_row_stat, 0, (size_t)n * ORBX_FAST_STAT_WORDS * 8, s));
   HIPCHK(c, mark(0, false));
+  OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2};
+  bool two_pass = false;
   if (fused_pyrblur(c)) {
     // blur on every level: pyramid and blur in one pass, the un-blurred pyramid is never materialised
     // (the event slots then read: pyramid = 0, blur = the fused kernel)
     HIPCHK(c, mark(1, true));
     // (a wave per strip: below ~4096 waves the chip is far from full and the short-band table wins)
     const bool small = (long long)n * c->pyrblur_tiles_count < 4096;
-    HIPCHK(c, orbx_launch_pyrblur(s, small ? c->d_tiles_pyrblur_small : c->d_tiles_pyrblur,
-                                  small ? c->pyrblur_small_count : c->pyrblur_tiles_count, P.frame_bytes, P.w0, P.h0, n,
-                                  d_frames, row_stride, frame_stride, c->d_taps, c->d_pyr_blur,
-                                  small ? 0 : pyr_group_env()));
+    // Top rows first.  The FAST early exit rests on the row-major cap (src/orb_cpu.cpp:108-110, src/orb.cpp:63):
+    // once the top tile rows of a level hold `cap` survivors, nothing below them is ever looked at -- not by
+    // FAST (its tiles exit), not by the selection (it stops at the first cap survivors), not by Harris or
+    // the descriptors (their keypoints lie in those top rows).  So the pyramid is produced in two passes:
+    //   1. the rows the first ORBX_TOP_ROWS FAST tile rows (and the descriptors of their keypoints) can read,
+    //   2. FAST on those tile rows,
+    //   3. the remaining rows -- a strip whose (frame, level) already has its cap survivors is skipped,
+    //   4. FAST on the remaining tile rows (their tiles exit the same way).
+    // What a skipped strip leaves in the pool (rows of an earlier batch) is never read.  Results are
+    // identical either way (tests/test_gpu_parity.py, tests/test_batch64_parity.py).
+    two_pass = !small && fast_early_on(c) && top_rows_env() > 0 && c->pyrblur_rest_count > 0 &&
+               c->bm_fast.nbands > top_rows_env();
+    if (!two_pass) {
+      HIPCHK(c, orbx_launch_pyrblur(s, small ? c->d_tiles_pyrblur_small : c->d_tiles_pyrblur,
+                                    small ? c->pyrblur_small_count : c->pyrblur_tiles_count, P.frame_bytes, P.w0, P.h0, n,
+                                    d_frames, row_stride, frame_stride, c->d_taps, c->d_pyr_blur,
+                                    small ? 0 : pyr_group_env()));
+    } else {
+      const int first_tiles = c->bm_fast.band_begin[top_rows_env()];
+      HIPCHK(c, orbx_launch_pyrblur(s, c->d_tiles_pyrblur_top, c->pyrblur_top_count, P.frame_bytes, P.w0, P.h0, n, d_frames,
+                                    row_stride, frame_stride, c->d_taps, c->d_pyr_blur, pyr_group_env()));
+      HIPCHK(c, mark(ORBX_NUM_STAGE_TIMES + 1, true));
+      HIPCHK(c, orbx_launch_fast_nms(s, c->d_tiles_fast, first_tiles, n, final_pyr(c), P.frame_bytes, P.mask_words, fp,
+                                     c->d_mask, nullptr, c->d_row_stat));
+      HIPCHK(c, mark(ORBX_NUM_STAGE_TIMES + 2, true));
+      HIPCHK(c, orbx_launch_pyrblur(s, c->d_tiles_pyrblur_rest, c->pyrblur_rest_count, P.frame_bytes, P.w0, P.h0, n,
+                                    d_frames, row_stride, frame_stride, c->d_taps, c->d_pyr_blur, pyr_group_env(),
+                                    c->d_row_stat));
+      HIPCHK(c, mark(2, true));
+      HIPCHK(c, orbx_launch_fast_nms(s, c->d_tiles_fast + first_tiles, c->fast_tiles_count - first_tiles, n, final_pyr(c),
+                                     P.frame_bytes, P.mask_words, fp, c->d_mask, nullptr, c->d_row_stat));
+    }
   } else {
     HIPCHK(c, launch_pyramid_auto(c, s, n, d_frames, row_stride, frame_stride));
     HIPCHK(c, mark(1, true));
@@ -709,9 +781,12 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
       HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->d_tiles_blur, c->blur_tiles_count, n, c->d_pyr,
                                  c->d_pyr_blur, c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
   }
-  HIPCHK(c, mark(2, true));
-  OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2};
-  HIPCHK(c, launch_fast_whole(c, s, n, fp, true));
+  if (!two_pass) {
+    HIPCHK(c, mark(2, true));
+    HIPCHK(c, launch_fast_whole(c, s, n, fp, true));
+  }
+  c->ev_split[c->ev_calls % ORBX_EVENT_SETS] = two_pass;
+  c->last_two_pass = two_pass;
   HIPCHK(c, mark(3, true));
   HIPCHK(c, mark(4, false));  // (compaction, Harris and selection are one kernel: its time is the "select" slot)
   HIPCHK(c, mark(5, false));
@@ -921,7 +996,7 @@ void orbx_destroy(orbx_ctx* c) {
   for (int i = 0; i < orbx_ctx::kGraphs; i++) drop_graph(c, i);
   void* bufs[] = {c->d_in,   c->d_pyr,  c->d_pyr_blur, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total,
                   c->d_resp, c->d_taps, c->d_gauss,    c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur, c->d_tiles_pyr2, c->d_tiles_pyrblur, c->d_tiles_pyrblur_small,
-                  c->d_lcand, c->d_lresp, c->d_lcount};
+                  c->d_tiles_pyrblur_top, c->d_tiles_pyrblur_rest, c->d_lcand, c->d_lresp, c->d_lcount};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 2; i++) {
@@ -1025,8 +1100,10 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
     build_pyrblur_tiles(M, ORBX_PYRBLUR_RH_SMALL, &t4);
     c->tiles_small_capacity = t4.size() + 64;
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_pyrblur_small, c->tiles_small_capacity * sizeof(OrbxTileDesc)));
-    c->tiles_frame_capacity = std::max(std::max(t1.size(), t2.size()), t3.size()) + 64;
+    c->tiles_frame_capacity = std::max(std::max(t1.size(), t2.size()), t3.size()) + 256;  // (+ the extra bands of a split table)
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_pyrblur, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
+    CREATE_CHK(hipMalloc((void**)&c->d_tiles_pyrblur_top, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
+    CREATE_CHK(hipMalloc((void**)&c->d_tiles_pyrblur_rest, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_blur, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_pyr2, c->tiles_frame_capacity * sizeof(OrbxTileDesc)));
   }
@@ -1160,6 +1237,33 @@ int orbx_fast_tile_counts(orbx_ctx* c, long long* worked, long long* total) {
   return ORBX_OK;
 }
 
+int orbx_pyramid_pixel_counts(orbx_ctx* c, long long* produced, long long* total) {
+  DeviceGuard _dg(c);
+  if (!c || !produced || !total) return ORBX_ERR_INVALID_ARG;
+  if (c->plan_w == 0 || c->last_n < 1) return fail(c, ORBX_ERR_INVALID_ARG, "run a batch first");
+  const int n = c->last_n, top = top_rows_env();
+  long long per_frame = 0;
+  for (int l = 0; l < c->plan.nlevels; l++) per_frame += (long long)c->plan.L[l].w * c->plan.L[l].h;
+  *total = per_frame * n;
+  *produced = *total;
+  if (!c->last_two_pass) return ORBX_OK;
+  std::vector<unsigned long long> h((size_t)n * ORBX_FAST_STAT_WORDS);
+  HIPCHK(c, hipStreamSynchronize(c->last_stream));
+  HIPCHK(c, hipMemcpy(h.data(), c->d_row_stat, h.size() * 8, hipMemcpyDeviceToHost));
+  long long done = 0;
+  for (int f = 0; f < n; f++)
+    for (int l = 0; l < c->plan.nlevels; l++) {
+      const OrbxLevel& L = c->plan.L[l];
+      const int first = pyrblur_first_pass_rows(c->plan, c->bm_fast, l, top);
+      long long surv = 0;  // the kernel's test: survivors of the first-pass tile rows
+      for (int b = 0; b < std::min(top, c->bm_fast.tiles_y[l]); b++)
+        surv += (long long)(uint32_t)h[(size_t)f * ORBX_FAST_STAT_WORDS + (size_t)l * ORBX_MAX_BANDS + b];
+      done += (long long)L.w * (first < L.h && surv >= L.cap ? first : L.h);
+    }
+  *produced = done;
+  return ORBX_OK;
+}
+
 int orbx_enable_stage_timing(orbx_ctx* c, int enable) {
   DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
@@ -1182,6 +1286,16 @@ int orbx_stage_times_history(orbx_ctx* c, int back, float* ms) {
   } else {  // blur and fast+nms only
     HIPCHK(c, hipEventElapsedTime(&ms[1], evs[1], evs[2]));
     HIPCHK(c, hipEventElapsedTime(&ms[2], evs[2], evs[3]));
+  }
+  if (c->ev_split[call % ORBX_EVENT_SETS]) {
+    // top-rows-first pipeline: events 1 | pyramid+blur (top) | N+1 | FAST (top) | N+2 | pyramid+blur (rest) | 2 | FAST (rest) | 3
+    float a = 0, b = 0, d = 0, e = 0;
+    HIPCHK(c, hipEventElapsedTime(&a, evs[1], evs[ORBX_NUM_STAGE_TIMES + 1]));
+    HIPCHK(c, hipEventElapsedTime(&b, evs[ORBX_NUM_STAGE_TIMES + 1], evs[ORBX_NUM_STAGE_TIMES + 2]));
+    HIPCHK(c, hipEventElapsedTime(&d, evs[ORBX_NUM_STAGE_TIMES + 2], evs[2]));
+    HIPCHK(c, hipEventElapsedTime(&e, evs[2], evs[3]));
+    ms[1] = a + d;
+    ms[2] = b + e;
   }
   return ORBX_OK;
 }

@@ -367,7 +367,8 @@ __device__ __forceinline__ void pyrblur_strip(const Blur3Strip& S, const PyrSrc&
 __global__ __launch_bounds__(256, 8) void k_pyrblur(const OrbxTileDesc* __restrict__ tiles, int n_tiles, int frame_bytes,
                                                  int w0, int h0, const uint8_t* __restrict__ in, int in_stride,
                                                  size_t in_frame_stride, const OrbxResizeTap* __restrict__ taps,
-                                                 uint8_t* __restrict__ dst, int group, int n_frames) {
+                                                 uint8_t* __restrict__ dst, int group, int n_frames,
+                                                 const u64* __restrict__ row_stat) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int wg = blockIdx.x, f = blockIdx.y;
   if (group) {
@@ -385,6 +386,21 @@ __global__ __launch_bounds__(256, 8) void k_pyrblur(const OrbxTileDesc* __restri
   const OrbxTileDesc d = tiles[ti];
   const int w = d.w, h = d.h, pitch = d.pitch;
   const int lane = threadIdx.x & 63;
+  // Second pass of the top-rows-first pipeline (orbx_api.cpp, enqueue_batch): the FAST tiles of the
+  // level's first `na` tile rows have all run (a launch earlier), and their survivor counts tell whether
+  // anything below can matter: keypoints are kept in ROW-MAJOR order up to `cap` (src/orb_cpu.cpp:108-110,
+  // src/orb.cpp:63), so once those rows hold >= cap survivors no later stage reads a pyramid row at or below
+  // this strip's first one (the host cuts the second-pass strips below the last row a descriptor of a
+  // keypoint in the top rows can reach), and the strip is not produced at all.
+  if (row_stat) {
+    const int na = (int)(d.mask_off >> 32), cap = (int)(uint32_t)d.mask_off;
+    if (na > 0) {
+      const u64* st = row_stat + (size_t)f * ORBX_FAST_STAT_WORDS + d.stat_index;
+      u64 v = 0;
+      if (lane < na) v = __hip_atomic_load(&st[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (wave_sum((int)(uint32_t)v) >= cap) return;  // whole wave
+    }
+  }
   // Strip s starts at dword 62 s: lanes 1..62 are productive, lane 0 / 63 hold the neighbours' dwords --
   // except at the image borders, where the neighbour is a REFLECTION the lane builds from its own dword:
   // lane 0 of the first strip and lane 63 of the last one are productive too (a 1241-px level needs
@@ -485,12 +501,13 @@ hipError_t orbx_launch_blur3(hipStream_t s, const OrbxTileDesc* d_tiles, int n_t
 // table of ONE frame (orbx_api.cpp: build_pyrblur_tiles)
 hipError_t orbx_launch_pyrblur(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int w0, int h0,
                                int n_frames, const uint8_t* d_in, int in_stride, size_t in_frame_stride,
-                               const OrbxResizeTap* d_taps, uint8_t* d_dst, int group) {
+                               const OrbxResizeTap* d_taps, uint8_t* d_dst, int group,
+                               const unsigned long long* d_row_stat) {
   if (n_tiles <= 0 || n_frames <= 0) return hipSuccess;
   if (group > 0) {
     const int nwg = (n_tiles + 3) / 4, ngroups = (n_frames + group - 1) / group;
     hipLaunchKernelGGL(k_pyrblur, dim3((unsigned)(ngroups * group * nwg)), dim3(256), 0, s, d_tiles, n_tiles, frame_bytes,
-                       w0, h0, d_in, in_stride, in_frame_stride, d_taps, d_dst, group, n_frames);
+                       w0, h0, d_in, in_stride, in_frame_stride, d_taps, d_dst, group, n_frames, d_row_stat);
     return hipGetLastError();
   }
   // Workgroups are dealt round-robin over the 8 XCDs in linear order (x fastest).  With a grid.x that
@@ -500,6 +517,6 @@ hipError_t orbx_launch_pyrblur(hipStream_t s, const OrbxTileDesc* d_tiles, int n
   // the assignment from frame to frame; the padding workgroup exits at once.
   dim3 grid(((n_tiles + 3) / 4) | 1, n_frames);
   hipLaunchKernelGGL(k_pyrblur, grid, dim3(256), 0, s, d_tiles, n_tiles, frame_bytes, w0, h0, d_in, in_stride,
-                     in_frame_stride, d_taps, d_dst, 0, n_frames);
+                     in_frame_stride, d_taps, d_dst, 0, n_frames, d_row_stat);
   return hipGetLastError();
 }

@@ -30,7 +30,7 @@ EXPORTS = [
     "orbx_wait", "orbx_batch_results_device", "orbx_batch_results_host", "orbx_batch_fetch", "orbx_batch_prefetch",
     "orbx_batch_fetch_previous", "orbx_enable_stage_timing",
     "orbx_last_stage_times", "orbx_stage_times_history", "orbx_bench_stage", "orbx_set_fast_early_exit",
-    "orbx_set_fused_pyramid_blur", "orbx_fast_tile_counts", "orbx_lk_track", "orbx_lk_pyramid_levels", "orbx_fast_score", "orbx_nms", "orbx_fast",
+    "orbx_set_fused_pyramid_blur", "orbx_fast_tile_counts", "orbx_pyramid_pixel_counts", "orbx_lk_track", "orbx_lk_pyramid_levels", "orbx_fast_score", "orbx_nms", "orbx_fast",
     "orbx_orientations", "orbx_brief", "orbx_harris", "orbx_blur5_sep", "orbx_blur5_273", "orbx_conv2d",
     "orbx_gaussian_blur_conv", "orbx_gaussian_kernel", "orbx_sobel", "orbx_build_pyramid_level",
     "orbx_select_top", "orbx_knn2", "orbx_match_ratio", "orbx_batch_match_consecutive", "orbx_batch_match_fetch",
@@ -309,6 +309,12 @@ class Context:
         """(tiles that did the full FAST/NMS work, all tiles) of the last whole-path batch."""
         w, t = C.c_longlong(0), C.c_longlong(0)
         self._chk(self._lib.orbx_fast_tile_counts(self._h, C.byref(w), C.byref(t)))
+        return w.value, t.value
+
+    def pyramid_pixel_counts(self):
+        """(pyramid pixels produced, all pyramid pixels) of the last whole-path batch (top-rows-first pipeline)."""
+        w, t = C.c_longlong(0), C.c_longlong(0)
+        self._chk(self._lib.orbx_pyramid_pixel_counts(self._h, C.byref(w), C.byref(t)))
         return w.value, t.value
 
     def last_stage_times(self, back=0):
