@@ -135,3 +135,59 @@ def test_dispatch_shape_switches_do_not_change_results(pkg, oracle_results, env)
     want = shard.descriptor_checksum([len(r["kps"]) for r in oracle_results], [r["desc"] for r in oracle_results])
     assert int(line[1]) == sum(len(r["kps"]) for r in oracle_results)
     assert int(line[2]) == want
+
+
+def test_top_rows_first_pipeline_with_sparse_and_bottom_heavy_frames(pkg, frames):
+    """The pyramid is built top rows first and the rest of a level only if its top tile rows did not reach
+    `cap` survivors (orbx_api.cpp, enqueue_batch).  Mixed batch: dense stream-A frames (rest skipped),
+    frames whose corners all lie in the BOTTOM half (everything has to be produced, keypoints far below the
+    first-pass rows), near-empty frames, and frames with a dense top band on some levels only -- every
+    frame compared with the oracle."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    mixed = frames.copy()
+    for i in range(B):
+        kind = i % 4
+        if kind == 1:  # corners only below row 200
+            img = np.full((H, W), 90, np.uint8)
+            for _ in range(400):
+                x, y = int(rng.integers(8, W - 40)), int(rng.integers(200, H - 30))
+                img[y:y + int(rng.integers(4, 24)), x:x + int(rng.integers(4, 30))] = int(rng.integers(0, 256))
+            mixed[i] = img
+        elif kind == 2:  # a handful of corners anywhere
+            img = np.full((H, W), 128, np.uint8)
+            for _ in range(6):
+                x, y = int(rng.integers(8, W - 40)), int(rng.integers(8, H - 30))
+                img[y:y + 12, x:x + 17] = 255
+            mixed[i] = img
+        elif kind == 3:  # fine texture in the top 60 rows (upper levels never reach their cap there), blocks below
+            img = np.full((H, W), 60, np.uint8)
+            img[:60] = rng.integers(0, 256, (60, W), dtype=np.uint8)
+            for _ in range(150):
+                x, y = int(rng.integers(8, W - 40)), int(rng.integers(70, H - 30))
+                img[y:y + int(rng.integers(6, 20)), x:x + int(rng.integers(6, 20))] = int(rng.integers(0, 256))
+            mixed[i] = img
+    op = O.gpu_params(**PK)
+    with cf.ThreadPoolExecutor(8) as ex:
+        refs = list(ex.map(lambda f: O.detect_and_compute_gpu(f, op), mixed))
+    p = pkg.default_params("gpu", max_width=W, max_height=H, max_batch=B, **PK)
+    with pkg.Context(p) as c:
+        cap = c.plan(W, H)["out_capacity"]
+        d = torch.from_numpy(mixed).cuda()
+        torch.cuda.synchronize()
+        # a first batch of other frames leaves ITS rows in the pool: a strip skipped now must not be read
+        d0 = torch.from_numpy(np.ascontiguousarray(mixed[::-1])).cuda()
+        c.batch_device(d0.data_ptr(), B, W, H)
+        c.wait()
+        for _ in range(2):
+            c.batch_device(d.data_ptr(), B, W, H)
+            res = c.batch_fetch(0, B, cap)
+            compare(res, refs, cap)
+        done, total = c.pyramid_pixel_counts()
+        assert 0 < done < total  # some levels skipped their lower rows, others did not
+        c.set_fast_early_exit(False)  # one pass, every row
+        c.batch_device(d.data_ptr(), B, W, H)
+        compare(c.batch_fetch(0, B, cap), refs, cap)
+        done, total = c.pyramid_pixel_counts()
+        assert done == total
