@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 runs of tools/pmc_collect.sh into profiles/r02/:
   *_kernel_stats.csv   per-kernel duration statistics (from the kernel traces)
-  pmc_counters.json    per-kernel counters per launch + the FETCH_SIZE / WRITE_SIZE calibration, stamped
+  pmc_counters.json    per-kernel counters per STEP + the FETCH_SIZE / WRITE_SIZE calibration, stamped
                        with the hash of the kernel sources (bench.py uses it only for the same sources)
 usage: pmc_to_json.py <collect dir> <profiles dir>"""
 import collections
@@ -19,22 +19,31 @@ def kname(s):
     return s.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
 
 
+STEP_KERNEL = "k_level_select"  # launched exactly once per step (batch): its dispatch count = steps of a run
+
+
 def trace_stats(d):
-    """kernel -> (calls, mean us, min us, max us) from a *_kernel_trace.csv"""
+    """kernel -> (calls, mean us, min us, max us, us per step) from a *_kernel_trace.csv.  A step of the
+    production pipeline launches k_pyrblur and k_fast3 TWICE (top rows first): `us per step` sums them."""
     out = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "*kernel_trace.csv")):
         for r in csv.DictReader(open(f)):
             out[kname(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    return {k: (len(v), sum(v) / len(v), min(v), max(v)) for k, v in out.items()}
+    steps = len(out.get(STEP_KERNEL, [])) or None
+    return {k: (len(v), sum(v) / len(v), min(v), max(v), sum(v) / steps if steps else sum(v) / len(v)) for k, v in out.items()}
 
 
-def counters(d):
-    """kernel -> counter -> mean per dispatch"""
+def counters(d, per_step=True):
+    """kernel -> counter -> mean per STEP (sum over the kernel's dispatches / steps of the run); per dispatch
+    for runs without the step kernel (the calibration probes)"""
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             agg[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: sum(x) / len(x) for c, x in v.items()} for k, v in agg.items()}
+    steps = 0
+    if per_step and STEP_KERNEL in agg:
+        steps = max(len(x) for x in agg[STEP_KERNEL].values())
+    return {k: {c: (sum(x) / steps if steps else sum(x) / len(x)) for c, x in v.items()} for k, v in agg.items()}
 
 
 def main():
@@ -52,10 +61,10 @@ def main():
         if not st:
             continue
         with open(os.path.join(dst, cfg + "_kernel_stats.csv"), "w") as f:
-            f.write("kernel,calls,avg_us,min_us,max_us\n")
-            for k, (n, a, lo, hi) in sorted(st.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
-                f.write("%s,%d,%.2f,%.2f,%.2f\n" % (k, n, a, lo, hi))
-        cfgd = {"avg_us": {k: v[1] for k, v in st.items()}}
+            f.write("kernel,calls,avg_us,min_us,max_us,us_per_step\n")
+            for k, (n, a, lo, hi, ps) in sorted(st.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+                f.write("%s,%d,%.2f,%.2f,%.2f,%.2f\n" % (k, n, a, lo, hi, ps))
+        cfgd = {"avg_us": {k: v[1] for k, v in st.items()}, "us_per_step": {k: v[4] for k, v in st.items()}}
         for part in ("sqa", "sqb", "fetch", "write"):
             c = counters(os.path.join(src, "%s_%s" % (cfg, part)))
             for k, v in c.items():
@@ -64,8 +73,8 @@ def main():
     # calibration: FETCH_SIZE / WRITE_SIZE (KB) against the bytes bw_probe really moves
     calib = {}
     for mb in (97, 1600):
-        f = counters(os.path.join(src, "calib_fetch_%d" % mb))
-        w = counters(os.path.join(src, "calib_write_%d" % mb))
+        f = counters(os.path.join(src, "calib_fetch_%d" % mb), per_step=False)
+        w = counters(os.path.join(src, "calib_write_%d" % mb), per_step=False)
         if f or w:
             calib[str(mb)] = {"fetch_kb": {k: v.get("FETCH_SIZE") for k, v in f.items()},
                               "write_kb": {k: v.get("WRITE_SIZE") for k, v in w.items()}}
@@ -74,14 +83,15 @@ def main():
     def pick(cfg, kern, key):
         return res["configs"].get(cfg, {}).get("counters", {}).get(kern, {}).get(key)
 
-    table = {"k_pyrblur": ("timed", "k_pyrblur"), "k_fast3": ("timed", "k_fast3<1>"),
+    table = {"k_pyrblur": ("timed", "k_pyrblur"), "k_pyrblur_every_row": ("fullwork", "k_pyrblur"),
+             "k_fast3": ("timed", "k_fast3<1>"),
              "k_fast3_full_work": ("fullwork", "k_fast3<1>"), "k_level_select": ("timed", "k_level_select"),
-             "k_describe2": ("timed", "k_describe2<4>"), "k_pyramid2": ("unfused", "k_pyramid2"),
+             "k_describe2": ("timed", "k_describe2<4, 8>"), "k_pyramid2": ("unfused", "k_pyramid2"),
              "k_blur3": ("unfused", "k_blur3")}
     for name, (cfg, kern) in table.items():
         valu, fe, wr = pick(cfg, kern, "SQ_INSTS_VALU"), pick(cfg, kern, "FETCH_SIZE"), pick(cfg, kern, "WRITE_SIZE")
         e = {"valu": valu, "fetch_kb": fe, "write_kb": wr, "config": cfg,
-             "avg_us_rocprof": res["configs"].get(cfg, {}).get("avg_us", {}).get(kern)}
+             "us_per_step_rocprof": res["configs"].get(cfg, {}).get("us_per_step", {}).get(kern)}
         # gfx950: FETCH_SIZE reports exactly half of the bytes of a coalesced streaming read, at 4, 8 and
         # 16 B per lane alike, Infinity-Cache hits included (calibration below; MI355X_MICROARCH.md §HBM);
         # WRITE_SIZE reads the written bytes exactly
