@@ -202,6 +202,15 @@ int orbx_set_fused_pyramid_blur(orbx_ctx* ctx, int enable);
  * exit.  With the early exit disabled worked == total. */
 int orbx_fast_tile_counts(orbx_ctx* ctx, long long* worked, long long* total);
 
+/* Top-rows-first pyramid (whole path, blur on every level, FAST early exit on, large batches): the pyramid
+ * rows the top FAST tile rows need are produced first, FAST runs on those tile rows, and the remaining rows
+ * of a level are produced only if the level does not yet hold its `cap` survivors -- keypoints are kept in
+ * row-major order up to the cap (src/orb_cpu.cpp:108-110, src/orb.cpp:63), so nothing below is ever read.
+ * Results are identical in every mode.  mode 0: never (one pass), 1: whenever eligible, 2 (default): adaptive
+ * -- the second pass reports how many levels it could skip, and while that is less than a quarter the batches
+ * run in one pass (with a probe every 128th batch). */
+int orbx_set_top_rows_first(orbx_ctx* ctx, int mode);
+
 /* Same for the pyramid: pyramid pixels the last whole-path batch PRODUCED out of all pyramid pixels of its
  * frames.  With blur on every level, the FAST early exit on and a large batch, the pyramid is built top rows
  * first and the remaining rows of a level are produced only if its top FAST tile rows did not already hold

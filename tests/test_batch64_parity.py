@@ -174,6 +174,7 @@ def test_top_rows_first_pipeline_with_sparse_and_bottom_heavy_frames(pkg, frames
     p = pkg.default_params("gpu", max_width=W, max_height=H, max_batch=B, **PK)
     with pkg.Context(p) as c:
         cap = c.plan(W, H)["out_capacity"]
+        c.set_top_rows_first(1)  # always (the adaptive default may decide that this batch does not pay)
         d = torch.from_numpy(mixed).cuda()
         torch.cuda.synchronize()
         # a first batch of other frames leaves ITS rows in the pool: a strip skipped now must not be read
@@ -191,3 +192,38 @@ def test_top_rows_first_pipeline_with_sparse_and_bottom_heavy_frames(pkg, frames
         compare(c.batch_fetch(0, B, cap), refs, cap)
         done, total = c.pyramid_pixel_counts()
         assert done == total
+
+
+def test_top_rows_first_adapts_to_the_stream(pkg, frames, oracle_results):
+    """Adaptive mode (default): the second pass reports how many levels it could skip; a stream on which it
+    skips (almost) nothing falls back to one pass after the first batches, a dense stream keeps two passes.
+    Results equal the oracle's throughout."""
+    import torch
+
+    sparse = np.full((B, H, W), 128, np.uint8)
+    rng = np.random.default_rng(5)
+    for i in range(B):
+        for _ in range(8):
+            x, y = int(rng.integers(8, W - 40)), int(rng.integers(8, H - 30))
+            sparse[i, y:y + 12, x:x + 17] = 255
+    op = O.gpu_params(**PK)
+    with cf.ThreadPoolExecutor(8) as ex:
+        refs = list(ex.map(lambda f: O.detect_and_compute_gpu(f, op), sparse))
+    p = pkg.default_params("gpu", max_width=W, max_height=H, max_batch=B, **PK)
+    with pkg.Context(p) as c:
+        cap = c.plan(W, H)["out_capacity"]
+        ds, dd = torch.from_numpy(sparse).cuda(), torch.from_numpy(frames).cuda()
+        torch.cuda.synchronize()
+        fracs = []
+        for _ in range(4):
+            c.batch_device(ds.data_ptr(), B, W, H)
+            compare(c.batch_fetch(0, B, cap), refs, cap)  # (fetch waits: the report of this batch has arrived)
+            done, total = c.pyramid_pixel_counts()
+            fracs.append(done / total)
+        assert fracs[-1] == 1.0  # one pass by now (two-pass batches of this stream produce everything as well)
+        c.set_top_rows_first(2)  # reset the verdict: a dense stream keeps its two passes
+        for _ in range(3):
+            c.batch_device(dd.data_ptr(), B, W, H)
+            compare(c.batch_fetch(0, B, cap), oracle_results, cap)
+            done, total = c.pyramid_pixel_counts()
+        assert done < 0.7 * total

@@ -62,7 +62,7 @@ OutLayout make_out_layout(int n, int cap) {
 struct OrbxGraphKey {
   const uint8_t* d_frames;
   size_t frame_stride;
-  int n, w, h, row_stride, early, plan_serial, block;
+  int n, w, h, row_stride, early, plan_serial, block;  // early: switches (early exit, fusion, two passes)
   bool operator==(const OrbxGraphKey& o) const {
     return d_frames == o.d_frames && frame_stride == o.frame_stride && n == o.n && w == o.w && h == o.h &&
            row_stride == o.row_stride && early == o.early && plan_serial == o.plan_serial && block == o.block;
@@ -159,6 +159,16 @@ struct orbx_ctx {
   int timing = 0;  // 0 off, 1 all stages, 2 blur + fast only
   int fast_early = 1;
   int fuse = 1;  // pyramid + blur in one kernel when blur runs on every level (orbx_set_fused_pyramid_blur)
+  // Top-rows-first pipeline (enqueue_batch): 0 never, 1 whenever eligible, 2 adaptive -- the second pass
+  // counts the (frame, level)s it skipped / had to produce (d_feedback, running totals, copied to the pinned
+  // h_feedback at the end of every two-pass batch and read WITHOUT waiting at the start of later ones); while
+  // fewer than a quarter are skipped the batches run in one pass, and every 128th one probes again.
+  int top_mode = 2;
+  bool top_on = true;          // the adaptive verdict
+  int top_single_batches = 0;  // one-pass batches since the verdict turned negative
+  uint32_t* d_feedback = nullptr;
+  volatile uint32_t* h_feedback = nullptr;
+  uint32_t feedback_seen[2] = {0, 0};
   // ring of event sets: one per timed batched call, so that several calls can be
   // in flight before their stage times are read (no host sync between steps)
   // (slots ORBX_NUM_STAGE_TIMES + 1, + 2: the boundaries inside the top-rows-first pipeline)
@@ -417,6 +427,7 @@ void build_pyrblur_tiles(const OrbxPlan& plan, int max_rows, std::vector<OrbxTil
         if (part == 2) {
           d.stat_index = (uint32_t)(l * ORBX_MAX_BANDS);
           d.mask_off = ((uint64_t)(uint32_t)std::min(top_rows, bm->tiles_y[l]) << 32) | (uint32_t)L.cap;
+          if (b == 0 && tx == 0) d.mask_off |= 1ull << 62;  // this strip reports the level's verdict
         }
         if (d.f > 0) out->push_back(d);
       }
@@ -720,6 +731,30 @@ hipError_t launch_blur_auto(hipStream_t s, const OrbxPlan& P, const OrbxTileMap&
 }
 const uint8_t* final_pyr(const orbx_ctx* c) { return blur_enabled(c) ? c->d_pyr_blur : c->d_pyr; }
 
+// Top-rows-first pipeline: wanted for the next batch?  (Eligibility -- fused kernel, early exit on, large
+// batch -- is checked where the launches are made.)
+bool top_rows_wanted(const orbx_ctx* c) {
+  if (top_rows_env() <= 0 || c->top_mode == 0) return false;
+  return c->top_mode == 1 || c->top_on;
+}
+// adaptive mode: look at the totals the second passes have reported so far (no waiting: whatever has arrived)
+void top_rows_update(orbx_ctx* c) {
+  if (c->top_mode != 2 || !c->h_feedback) return;
+  const uint32_t sk = c->h_feedback[0], pr = c->h_feedback[1];
+  const uint32_t dsk = sk - c->feedback_seen[0], dpr = pr - c->feedback_seen[1];
+  if (dsk + dpr > 0) {
+    c->feedback_seen[0] = sk;
+    c->feedback_seen[1] = pr;
+    const bool pays = 4ull * dsk >= (unsigned long long)(dsk + dpr);  // a quarter of the levels skipped
+    if (!pays && c->top_on) c->top_single_batches = 0;
+    c->top_on = pays;
+  }
+  if (!c->top_on && ++c->top_single_batches >= 128) {  // probe again
+    c->top_on = true;
+    c->top_single_batches = 0;
+  }
+}
+
 // the launches of the whole path for n frames already on the device (the plan is set)
 int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, size_t frame_stride, hipStream_t s) {
   const OrbxPlan& P = c->plan;
@@ -752,7 +787,7 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
     //   4. FAST on the remaining tile rows (their tiles exit the same way).
     // What a skipped strip leaves in the pool (rows of an earlier batch) is never read.  Results are
     // identical either way (tests/test_gpu_parity.py, tests/test_batch64_parity.py).
-    two_pass = !small && fast_early_on(c) && top_rows_env() > 0 && c->pyrblur_rest_count > 0 &&
+    two_pass = !small && fast_early_on(c) && top_rows_wanted(c) && c->pyrblur_rest_count > 0 &&
                c->bm_fast.nbands > top_rows_env();
     if (!two_pass) {
       HIPCHK(c, orbx_launch_pyrblur(s, small ? c->d_tiles_pyrblur_small : c->d_tiles_pyrblur,
@@ -769,10 +804,11 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
       HIPCHK(c, mark(ORBX_NUM_STAGE_TIMES + 2, true));
       HIPCHK(c, orbx_launch_pyrblur(s, c->d_tiles_pyrblur_rest, c->pyrblur_rest_count, P.frame_bytes, P.w0, P.h0, n,
                                     d_frames, row_stride, frame_stride, c->d_taps, c->d_pyr_blur, pyr_group_env(),
-                                    c->d_row_stat));
+                                    c->d_row_stat, c->d_feedback));
       HIPCHK(c, mark(2, true));
       HIPCHK(c, orbx_launch_fast_nms(s, c->d_tiles_fast + first_tiles, c->fast_tiles_count - first_tiles, n, final_pyr(c),
                                      P.frame_bytes, P.mask_words, fp, c->d_mask, nullptr, c->d_row_stat));
+      HIPCHK(c, hipMemcpyAsync(const_cast<uint32_t*>(c->h_feedback), c->d_feedback, 8, hipMemcpyDeviceToHost, s));
     }
   } else {
     HIPCHK(c, launch_pyramid_auto(c, s, n, d_frames, row_stride, frame_stride));
@@ -828,6 +864,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   if (c->last_stream && c->last_stream != s) HIPCHK(c, hipStreamSynchronize(c->last_stream));
   int st = set_plan(c, w, h);
   if (st != ORBX_OK) return st;
+  top_rows_update(c);
   // this batch writes the other result block; if that block is still the source of an
   // asynchronous D2H copy (orbx_batch_prefetch two batches ago), the kernels wait for the copy
   const int blk = c->blk ^ 1;
@@ -841,7 +878,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   }();
   const int tm = c->timing;
   if (use_graph && tm == 0) {
-    const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, (fast_early_on(c) ? 1 : 0) | (fused_pyrblur(c) ? 2 : 0),
+    const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, (fast_early_on(c) ? 1 : 0) | (fused_pyrblur(c) ? 2 : 0) | (top_rows_wanted(c) ? 4 : 0),
                            c->plan_serial, blk};
     int gi = -1;
     for (int i = 0; i < orbx_ctx::kGraphs; i++)
@@ -996,9 +1033,10 @@ void orbx_destroy(orbx_ctx* c) {
   for (int i = 0; i < orbx_ctx::kGraphs; i++) drop_graph(c, i);
   void* bufs[] = {c->d_in,   c->d_pyr,  c->d_pyr_blur, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total,
                   c->d_resp, c->d_taps, c->d_gauss,    c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur, c->d_tiles_pyr2, c->d_tiles_pyrblur, c->d_tiles_pyrblur_small,
-                  c->d_tiles_pyrblur_top, c->d_tiles_pyrblur_rest, c->d_lcand, c->d_lresp, c->d_lcount};
+                  c->d_tiles_pyrblur_top, c->d_tiles_pyrblur_rest, c->d_feedback, c->d_lcand, c->d_lresp, c->d_lcount};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  if (c->h_feedback) (void)hipHostFree(const_cast<uint32_t*>(c->h_feedback));
   for (int i = 0; i < 2; i++) {
     if (c->h_outb[i]) (void)hipHostFree(c->h_outb[i]);
     if (c->d_outb[i]) (void)hipFree(c->d_outb[i]);
@@ -1084,6 +1122,10 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_pyr_blur, B * (size_t)M.frame_bytes + 256));
   CREATE_CHK(hipMalloc((void**)&c->d_mask, B * (size_t)M.mask_words * 8 + 256));
   CREATE_CHK(hipMalloc((void**)&c->d_row_stat, B * ORBX_FAST_STAT_WORDS * 8));
+  CREATE_CHK(hipMalloc((void**)&c->d_feedback, 8));
+  CREATE_CHK(hipMemset(c->d_feedback, 0, 8));
+  CREATE_CHK(hipHostMalloc((void**)&c->h_feedback, 8, hipHostMallocDefault));
+  c->h_feedback[0] = c->h_feedback[1] = 0;
   {
     OrbxBandMap bmm;
     if ((st = make_bandmap(M, p->nms_window / 2, &bmm, &why)) != ORBX_OK) {
@@ -1216,6 +1258,15 @@ int orbx_set_fused_pyramid_blur(orbx_ctx* c, int enable) {
   DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   c->fuse = enable != 0;
+  return ORBX_OK;
+}
+
+int orbx_set_top_rows_first(orbx_ctx* c, int mode) {
+  DeviceGuard _dg(c);
+  if (!c || mode < 0 || mode > 2) return ORBX_ERR_INVALID_ARG;
+  c->top_mode = mode;
+  c->top_on = true;
+  c->top_single_batches = 0;
   return ORBX_OK;
 }
 

@@ -72,7 +72,8 @@ struct OrbxBandMap {
 //   blur         : one entry per (level, 256-px strip, row band): tx = strip, ty = first row,
 //                  f = rows of the band.
 //                  fused pyramid + blur, second pass of the top-rows-first pipeline: stat_index = first
-//                  tile-row statistic of the level, mask_off = (FAST tile rows of the first pass) << 32 | cap.
+//                  tile-row statistic of the level, mask_off = (FAST tile rows of the first pass) << 32 | cap,
+//                  bit 62 set in ONE strip per level (it reports whether the level was skipped).
 //   img_off / mask_off are offsets inside one frame's pyramid / mask block.
 struct OrbxTileDesc {
   int32_t l, tx, ty, f;
@@ -158,7 +159,7 @@ hipError_t orbx_launch_blur3(hipStream_t s, const OrbxTileDesc* d_tiles, int n_t
 hipError_t orbx_launch_pyrblur(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int w0, int h0,
                                int n_frames, const uint8_t* d_in, int in_stride, size_t in_frame_stride,
                                const OrbxResizeTap* d_taps, uint8_t* d_dst, int group = 0,
-                               const unsigned long long* d_row_stat = nullptr);
+                               const unsigned long long* d_row_stat = nullptr, uint32_t* d_feedback = nullptr);
 // d_tiles: n_tiles OrbxTileDesc in band-major order (orbx_api.cpp: build_fast_tiles, tile height
 // orbx_fast3_tile_h(fp.nms_radius)); d_scores: optional dense u16 score map of ONE frame (stage operator)
 hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int n_frames,
