@@ -416,7 +416,10 @@ def test_fast_tile_counts(pkg, kitti0, kitti1):
         c.set_fast_early_exit(False)
         c.batch_host(frames)
         w0, t0 = c.fast_tile_counts()
-        assert w0 == t0 and t0 == 8 * 239  # 239 tiles of 128x54 over the 8 levels of a 1241x376 frame
+        plan = c.plan(1241, 376)
+        tile_h = 47  # orbx_fast3_tile_h(1): 7 row segments x 7 rows per walk - 2 x NMS radius
+        per_frame = sum(-(-int(w) // 128) * -(-int(h) // tile_h) for w, h in zip(plan["level_w"], plan["level_h"]))
+        assert w0 == t0 and t0 == 8 * per_frame == 8 * 272  # tiles of 128 x <= 47 over the 8 levels of a 1241x376 frame
         c.set_fast_early_exit(True)
         c.batch_host(frames)
         w1, t1 = c.fast_tile_counts()

@@ -807,7 +807,7 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
                                     c->d_row_stat, c->d_feedback));
       HIPCHK(c, mark(2, true));
       HIPCHK(c, orbx_launch_fast_nms(s, c->d_tiles_fast + first_tiles, c->fast_tiles_count - first_tiles, n, final_pyr(c),
-                                     P.frame_bytes, P.mask_words, fp, c->d_mask, nullptr, c->d_row_stat));
+                                     P.frame_bytes, P.mask_words, fp, c->d_mask, nullptr, c->d_row_stat, 4));
       HIPCHK(c, hipMemcpyAsync(const_cast<uint32_t*>(c->h_feedback), c->d_feedback, 8, hipMemcpyDeviceToHost, s));
     }
   } else {

@@ -7,19 +7,21 @@
 // them the pre-test walk), and each tile's life is a chain of latencies (tile record, image rows, four
 // barriers, mask store) that six resident workgroups per CU only partly hide -- so the design is about
 // wave-instructions per pixel AND about taking latencies off that chain:
-//   Tiles are 128 pixels wide and up to 56 - 2R rows tall; the host balances the tile rows of a
-//   level (a 218-row level gets 5 tile rows of 44, not 4 of 54 and one of 2), and the walking
-//   threads then take 7 instead of 8 rows each.  A workgroup handles two consecutive tiles (the same
+//   Tiles are 128 pixels wide and up to 49 - 2R rows tall (7 row segments x 7 rows per walk; 8 rows per
+//   walk cost the same per pixel, but shorter tile rows make the first pass of the top-rows-first pipeline
+//   smaller: orbx_api.cpp, enqueue_batch); the host balances the tile rows of a level (a 218-row level
+//   gets 5 tile rows of 44, not 4 of 47 and one of 30), and the walking threads then take 6 instead of 7
+//   rows each.  A workgroup handles two consecutive tiles (the same
 //   tile of two consecutive frames); the second tile's rows are requested while the first one's
 //   candidates are evaluated.
 //   phase 1  tile + halo -> LDS, row-coalesced 8-byte loads at addresses clamped into the level
 //            (what the tile holds outside the image is never looked at).
 //   phase 2  4-point pre-test on EVERY pixel.  A thread owns one dword column (4 pixels) of the
-//            score region and walks K = 8 rows of it: each image row is unpacked ONCE into packed
+//            score region and walks K = 7 rows of it: each image row is unpacked ONCE into packed
 //            16-bit pairs (2 v_perm) and then serves as north row, centre row and south row of three
 //            different steps; the pre-test itself is a 8-op v_pk_min/max_u16 network per pixel pair
 //            (2nd smallest / 2nd largest of N,E,S,W) + 4 packed ops for both polarities.  The
-//            candidate flags of the 8 rows x 4 pixels end up in one register per thread.
+//            candidate flags of the 7 rows x 4 pixels end up in one register per thread.
 //   phase 3  the candidates (~3-6 % of the pixels) are compacted into one LDS queue (wave prefix sums,
 //            one LDS atomic per wave) and evaluated 64 at a time: one ring pixel per ds_read_u8, the
 //            16 comparisons per polarity shifted into a 16-bit mask per lane, the 9-contiguous-arc
@@ -55,7 +57,7 @@ struct F3 {
   static constexpr int QCAP = 736;               // candidate queue entries (more candidates: several passes)
   static constexpr int MASK_DW = TW / 32;        // mask dwords per tile row
 };
-static_assert(F3<1>::NC == 34 && F3<1>::NSEG == 7 && F3<1>::K == 8, "walk mapping (tid / 34 by multiply-shift) assumes 34 x 7");
+static_assert(F3<1>::NC == 34 && F3<1>::NSEG == 7 && F3<1>::K <= 8, "walk mapping (tid / 34 by multiply-shift) assumes 34 x 7; a flag byte holds <= 8 rows");
 static_assert(F3<0>::TH == orbx_fast3_tile_h(0) && F3<3>::TH == orbx_fast3_tile_h(3), "host tile tables use orbx_fast3_tile_h");
 
 // pre-test of the two pixels in the 16-bit lanes of `ip`: sign bit of a lane SET = not a candidate.
@@ -107,7 +109,7 @@ __device__ __forceinline__ uint32_t f3_walk(const uint32_t* p, uint32_t T, int k
       acc = (F & 0x80808080u) | (acc >> 1);
     }
   }
-  return ~acc >> (G::K - keff);  // (fewer than K steps: the rows have not travelled all the way down)
+  return ~acc >> (8 - keff);  // (fewer than 8 steps: the rows have not travelled all the way down the byte)
 }
 
 // run of >= n set bits in the circular 16-bit mask (any n; per-lane arithmetic)
@@ -566,14 +568,18 @@ __global__ __launch_bounds__(256, 6) void k_fast3(const OrbxTileDesc* __restrict
 template <int R>
 void launch_fast3(long long total, hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int n_frames, const uint8_t* d_pyr,
                   int frame_bytes, int mask_words, OrbxFastParams fp, unsigned long long* d_mask, uint16_t* d_scores,
-                  unsigned long long* d_row_stat) {
+                  unsigned long long* d_row_stat, int chunk_scale) {
   // tiles per workgroup (ORBX_FAST_CHUNK: A/B timing; results do not depend on it).  Small launches keep
-  // one tile per workgroup: the chip is not full anyway
+  // one tile per workgroup: the chip is not full anyway.  chunk_scale: the second launch of the
+  // top-rows-first pipeline, whose tiles nearly all exit, takes four times as many per workgroup (a
+  // workgroup probes four tiles per round trip).
   static const int chunk_env = [] {
     const char* e = getenv("ORBX_FAST_CHUNK");
     return e ? atoi(e) : 2;
   }();
-  const int chunk = total >= 8192 ? std::min(std::max(chunk_env, 1), 64) : 1;
+  // (never so many per workgroup that fewer than ~8192 workgroups remain: the chip holds 1536 at once)
+  const int wanted = std::min(std::max(chunk_env, 1) * std::max(chunk_scale, 1), 64);
+  const int chunk = (int)std::max<long long>(1, std::min<long long>(wanted, total / 8192));
   const int wgs = (int)((total + chunk - 1) / chunk);
   hipLaunchKernelGGL((k_fast3<R>), dim3(wgs), dim3(256), 0, s, d_tiles, n_tiles, n_frames, chunk, d_pyr, frame_bytes,
                      mask_words, fp, d_mask, d_scores, d_row_stat);
@@ -586,22 +592,27 @@ void launch_fast3(long long total, hipStream_t s, const OrbxTileDesc* d_tiles, i
 // d_row_stat: n_frames * ORBX_FAST_STAT_WORDS zeroed u64 (or NULL: no early exit)
 hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int n_frames,
                                 const uint8_t* d_pyr, int frame_bytes, int mask_words, OrbxFastParams fp,
-                                unsigned long long* d_mask, uint16_t* d_scores, unsigned long long* d_row_stat) {
+                                unsigned long long* d_mask, uint16_t* d_scores, unsigned long long* d_row_stat,
+                                int chunk_scale) {
   if (n_tiles <= 0 || n_frames <= 0) return hipSuccess;
   const long long total = (long long)n_tiles * n_frames;
   if (total > 0x7fffffffll) return hipErrorInvalidValue;
   switch (fp.nms_radius) {
     case 0:
-      launch_fast3<0>(total, s, d_tiles, n_tiles, n_frames, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores, d_row_stat);
+      launch_fast3<0>(total, s, d_tiles, n_tiles, n_frames, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores, d_row_stat,
+                      chunk_scale);
       break;
     case 1:
-      launch_fast3<1>(total, s, d_tiles, n_tiles, n_frames, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores, d_row_stat);
+      launch_fast3<1>(total, s, d_tiles, n_tiles, n_frames, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores, d_row_stat,
+                      chunk_scale);
       break;
     case 2:
-      launch_fast3<2>(total, s, d_tiles, n_tiles, n_frames, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores, d_row_stat);
+      launch_fast3<2>(total, s, d_tiles, n_tiles, n_frames, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores, d_row_stat,
+                      chunk_scale);
       break;
     default:
-      launch_fast3<3>(total, s, d_tiles, n_tiles, n_frames, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores, d_row_stat);
+      launch_fast3<3>(total, s, d_tiles, n_tiles, n_frames, d_pyr, frame_bytes, mask_words, fp, d_mask, d_scores, d_row_stat,
+                      chunk_scale);
       break;
   }
   return hipGetLastError();

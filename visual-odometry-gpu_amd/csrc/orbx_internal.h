@@ -99,10 +99,10 @@ struct OrbxFastParams {
 };
 
 // tile geometry of the FAST/NMS kernel (orbx_fast.hip): 128 output pixels wide (two mask words per
-// row); 34 dword columns x 7 row segments of walking threads, 8 rows per walk, so the score region
-// of a tile has 56 rows and a tile 56 - 2 * nms_radius output rows
+// row); 34 dword columns x 7 row segments of walking threads, 7 rows per walk (at most 8: a flag byte per
+// pixel column), so the score region of a tile has 49 rows and a tile 49 - 2 * nms_radius output rows
 #define ORBX_FAST3_TW 128
-#define ORBX_FAST3_K 8
+#define ORBX_FAST3_K 7
 constexpr int orbx_fast3_tile_h(int nms_radius) {
   return (256 / (ORBX_FAST3_TW / 4 + 2)) * ORBX_FAST3_K - 2 * nms_radius;
 }
@@ -165,7 +165,7 @@ hipError_t orbx_launch_pyrblur(hipStream_t s, const OrbxTileDesc* d_tiles, int n
 hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int n_frames,
                                 const uint8_t* d_pyr, int frame_bytes, int mask_words, OrbxFastParams fp,
                                 unsigned long long* d_mask, uint16_t* d_scores,
-                                unsigned long long* d_row_stat);
+                                unsigned long long* d_row_stat, int chunk_scale = 1);
 hipError_t orbx_launch_compact(hipStream_t s, const OrbxPlan& plan, int n_frames,
                                const unsigned long long* d_mask, orbx_keypoint* d_cand, int32_t* d_cand_count,
                                int32_t* d_cand_total, int need_total);
