@@ -86,7 +86,7 @@ def main():
     table = {"k_pyrblur": ("timed", "k_pyrblur"), "k_pyrblur_every_row": ("fullwork", "k_pyrblur"),
              "k_fast3": ("timed", "k_fast3<1>"),
              "k_fast3_full_work": ("fullwork", "k_fast3<1>"), "k_level_select": ("timed", "k_level_select"),
-             "k_describe2": ("timed", "k_describe2<4, 8>"), "k_pyramid2": ("unfused", "k_pyramid2"),
+             "k_describe2": ("timed", "k_describe2<4, 4, 7>"), "k_pyramid2": ("unfused", "k_pyramid2"),
              "k_blur3": ("unfused", "k_blur3")}
     for name, (cfg, kern) in table.items():
         valu, fe, wr = pick(cfg, kern, "SQ_INSTS_VALU"), pick(cfg, kern, "FETCH_SIZE"), pick(cfg, kern, "WRITE_SIZE")

@@ -1167,7 +1167,15 @@ __device__ __forceinline__ void desc_fetch_patch(const DescJob& jb, int lane, ui
   }
 }
 
-__device__ __forceinline__ void desc_store_patch(DescLds& lds, int lane, const uint32_t (&regs)[DESC_NLD]) {
+// per-wavefront LDS working set of k_describe2: its box table is written over `hs`, the patch stays intact, so
+// there is no separate table (5.1 KB per wave instead of 6.1)
+struct DescLds2 {
+  uint32_t patch[DESC_ROWS * DESC_PITCH / 4];  // 41 x 48 u8
+  uint16_t hs[DESC_ROWS * DESC_HP];            // horizontal 5-sums, then (37 rows) the 5x5 box sums
+};
+
+template <class L>
+__device__ __forceinline__ void desc_store_patch(L& lds, int lane, const uint32_t (&regs)[DESC_NLD]) {
 #pragma unroll
   for (int k = 0; k < DESC_NLD; k++)
     if (lane + 64 * k < DESC_ROWS * (DESC_PITCH / 4)) lds.patch[lane + 64 * k] = regs[k];
@@ -1194,7 +1202,8 @@ __device__ __forceinline__ DescJob desc_job(const OrbxPlan& plan, const uint8_t*
 // registers.  The table (37 x DESC_HP u16) is written over lds.hs; the patch stays intact.
 // LDS traffic per keypoint: 11 reads + 7 writes per lane instead of 32 accesses for two
 // separate passes through an intermediate hs array.
-__device__ __forceinline__ void desc_box_table_fused(DescLds& lds, int lane) {
+template <class L>
+__device__ __forceinline__ void desc_box_table_fused(L& lds, int lane) {
   static_assert(DESC_BROWS == 37, "6 chunks: 7 + 5 x 6 rows");
   const int chunk = lane / 10, g = lane - chunk * 10;
   if (chunk < 6) {
@@ -1242,8 +1251,8 @@ __device__ __forceinline__ f2_t lround_f2(f2_t v) {
   return t + __builtin_elementwise_trunc(fr + fr);
 }
 
-template <int DESC_KPW, int DESC_NW>
-__global__ __launch_bounds__(64 * DESC_NW) void k_describe2(OrbxPlan plan, const uint8_t* __restrict__ pyr, int patch_size,
+template <int DESC_KPW, int DESC_NW, int DESC_OCC>
+__global__ __launch_bounds__(64 * DESC_NW, DESC_OCC) void k_describe2(OrbxPlan plan, const uint8_t* __restrict__ pyr, int patch_size,
                                                    const int32_t* __restrict__ sel_count,
                                                    const orbx_keypoint* __restrict__ sel_lkp,
                                                    const float* __restrict__ sel_resp,
@@ -1256,7 +1265,7 @@ __global__ __launch_bounds__(64 * DESC_NW) void k_describe2(OrbxPlan plan, const
                                                    orbx_descriptor* __restrict__ out_desc) {
   constexpr int DESC_KPB = DESC_NW * DESC_KPW;
   static_assert(2 * DESC_KPB <= 64 * DESC_NW, "trig: two threads per keypoint");
-  __shared__ __attribute__((aligned(16))) DescLds s_lds[DESC_NW];
+  __shared__ __attribute__((aligned(16))) DescLds2 s_lds[DESC_NW];
   __shared__ int s_m[DESC_KPB][2];
   __shared__ float s_cs[DESC_KPB][2];
   __shared__ uint2 s_mw[4 * (DESC_PITCH / 4)];
@@ -1274,7 +1283,7 @@ __global__ __launch_bounds__(64 * DESC_NW) void k_describe2(OrbxPlan plan, const
   if (grp == 0 && tid == 0) out_count[f] = count;
   const int slot0 = grp * DESC_KPB;
   if (slot0 >= count) return;  // whole workgroup
-  DescLds& lds = s_lds[wave];
+  DescLds2& lds = s_lds[wave];
   const int pr = patch_size / 2;
   // moment weights of the four bytes of patch dword column c when the keypoint's patch starts
   // `off` bytes into its first dword: {x - x_kp + pr for bytes inside the orientation window
@@ -1694,12 +1703,14 @@ hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frame
   // workgroups, a quarter of the serial work per wave; else four per wave
   if ((long long)plan.out_cap * n_frames <= 8192) {
     dim3 grid(n_frames, (plan.out_cap + 3) / 4);
-    hipLaunchKernelGGL((k_describe2<1, 4>), grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
+    hipLaunchKernelGGL((k_describe2<1, 4, 1>), grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
                        d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc);
   } else {
-    // eight waves of four keypoints: the 64 trig threads (two per keypoint) fill one wave
-    dim3 grid(n_frames, (plan.out_cap + 31) / 32);
-    hipLaunchKernelGGL((k_describe2<4, 8>), grid, dim3(512), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
+    // Four waves of four keypoints, registers capped for 7 waves per SIMD (5.1 KB of LDS per wave: 7 workgroups
+    // per CU).  Measured per 256 frames: 8-wave workgroups at 6 waves per SIMD (the trig -- two threads per
+    // keypoint -- fills a wave: -1.8 % instructions) 203 us, 7-wave workgroups 221 us, this 197 us.
+    dim3 grid(n_frames, (plan.out_cap + 15) / 16);
+    hipLaunchKernelGGL((k_describe2<4, 4, 7>), grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
                        d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc);
   }
   return ORBX_LAUNCH_CHECK();
