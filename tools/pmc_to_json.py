@@ -63,7 +63,7 @@ def main():
         with open(os.path.join(dst, cfg + "_kernel_stats.csv"), "w") as f:
             f.write("kernel,calls,avg_us,min_us,max_us,us_per_step\n")
             for k, (n, a, lo, hi, ps) in sorted(st.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
-                f.write("%s,%d,%.2f,%.2f,%.2f,%.2f\n" % (k, n, a, lo, hi, ps))
+                f.write('"%s",%d,%.2f,%.2f,%.2f,%.2f\n' % (k, n, a, lo, hi, ps))
         cfgd = {"avg_us": {k: v[1] for k, v in st.items()}, "us_per_step": {k: v[4] for k, v in st.items()}}
         for part in ("sqa", "sqb", "fetch", "write"):
             c = counters(os.path.join(src, "%s_%s" % (cfg, part)))
