@@ -285,6 +285,19 @@ def test_error_paths(pkg):
         pkg.Context(pkg.default_params("gpu", n=17))
     with pytest.raises(pkg.OrbxError):  # level 15 of a 64x64 frame is < 8x8
         pkg.Context(pkg.default_params("gpu", nlevels=16, max_width=64, max_height=64))
+    with pkg.Context(pkg.default_params("gpu", max_width=64, max_height=64)) as c:
+        with pytest.raises(pkg.OrbxError):  # diagnostics of the last batch: there is none yet
+            c.pyramid_pixel_counts()
+        with pytest.raises(pkg.OrbxError):
+            c.fast_tile_counts()
+        for bad in (-1, 3):
+            with pytest.raises(pkg.OrbxError):
+                c.set_top_rows_first(bad)
+        for ok in (0, 1, 2):
+            c.set_top_rows_first(ok)
+        c.batch_host(np.zeros((1, 64, 64), np.uint8))  # a batch too small for two passes: every pixel produced
+        done, total = c.pyramid_pixel_counts()
+        assert done == total > 0
 
 
 def test_fast_early_exit_is_invisible(pkg, kitti0, kitti1):
