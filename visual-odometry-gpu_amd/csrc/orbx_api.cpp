@@ -97,6 +97,7 @@ struct orbx_ctx {
   OrbxTileDesc* d_tiles_pyrblur_top = nullptr;
   OrbxTileDesc* d_tiles_pyrblur_rest = nullptr;
   int pyrblur_top_count = 0, pyrblur_rest_count = 0;
+  OrbxTopLevels top_levels{};  // the levels the second pass may skip
   size_t tiles_frame_capacity = 0, tiles_small_capacity = 0;
   int blur_tiles_count = 0, pyr2_tiles_count = 0;
   DevBuf s_tiles;  // stage-API tables
@@ -398,6 +399,7 @@ int pyrblur_first_pass_rows(const OrbxPlan& plan, const OrbxBandMap& bm, int l, 
 void build_pyrblur_tiles(const OrbxPlan& plan, int max_rows, std::vector<OrbxTileDesc>* out, bool heavy_first = false,
                          int part = 0, const OrbxBandMap* bm = nullptr, int top_rows = 0) {
   out->clear();
+  bool have_reporter = false;
   for (int l = 0; l < plan.nlevels; l++) {
     const OrbxLevel& L = plan.L[l];
     // dwords that hold image pixels: 62 per strip, one more in the first and in the last strip (their
@@ -427,7 +429,10 @@ void build_pyrblur_tiles(const OrbxPlan& plan, int max_rows, std::vector<OrbxTil
         if (part == 2) {
           d.stat_index = (uint32_t)(l * ORBX_MAX_BANDS);
           d.mask_off = ((uint64_t)(uint32_t)std::min(top_rows, bm->tiles_y[l]) << 32) | (uint32_t)L.cap;
-          if (b == 0 && tx == 0) d.mask_off |= 1ull << 62;  // this strip reports the level's verdict
+          if (b == 0 && tx == 0 && !have_reporter) {  // this strip's wave reports the verdicts of all the frame's levels
+            d.mask_off |= 1ull << 62;
+            have_reporter = true;
+          }
         }
         if (d.f > 0) out->push_back(d);
       }
@@ -652,6 +657,14 @@ int set_plan(orbx_ctx* c, int w, int h) {
     if (!t.empty())
       HIPCHK(c, hipMemcpy(c->d_tiles_pyrblur_rest, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
     c->pyrblur_rest_count = (int)t.size();
+    c->top_levels = OrbxTopLevels{};
+    for (int l = 0; l < plan.nlevels; l++)
+      if (pyrblur_first_pass_rows(plan, c->bm_fast, l, top_rows_env()) < plan.L[l].h) {
+        const int i = c->top_levels.n++;
+        c->top_levels.stat_index[i] = l * ORBX_MAX_BANDS;
+        c->top_levels.rows[i] = std::min(top_rows_env(), c->bm_fast.tiles_y[l]);
+        c->top_levels.cap[i] = plan.L[l].cap;
+      }
     build_pyrblur_tiles(plan, ORBX_PYRBLUR_RH_SMALL, &t);
     if (t.size() > c->tiles_small_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "strip table exceeds pool");
     HIPCHK(c, hipMemcpy(c->d_tiles_pyrblur_small, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
@@ -804,7 +817,7 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
       HIPCHK(c, mark(ORBX_NUM_STAGE_TIMES + 2, true));
       HIPCHK(c, orbx_launch_pyrblur(s, c->d_tiles_pyrblur_rest, c->pyrblur_rest_count, P.frame_bytes, P.w0, P.h0, n,
                                     d_frames, row_stride, frame_stride, c->d_taps, c->d_pyr_blur, pyr_group_env(),
-                                    c->d_row_stat, c->d_feedback));
+                                    c->d_row_stat, c->d_feedback, &c->top_levels));
       HIPCHK(c, mark(2, true));
       HIPCHK(c, orbx_launch_fast_nms(s, c->d_tiles_fast + first_tiles, c->fast_tiles_count - first_tiles, n, final_pyr(c),
                                      P.frame_bytes, P.mask_words, fp, c->d_mask, nullptr, c->d_row_stat, 4));

@@ -73,7 +73,7 @@ struct OrbxBandMap {
 //                  f = rows of the band.
 //                  fused pyramid + blur, second pass of the top-rows-first pipeline: stat_index = first
 //                  tile-row statistic of the level, mask_off = (FAST tile rows of the first pass) << 32 | cap,
-//                  bit 62 set in ONE strip per level (it reports whether the level was skipped).
+//                  bit 62 set in ONE strip per frame (its wave reports how many levels of the frame were skipped).
 //   img_off / mask_off are offsets inside one frame's pyramid / mask block.
 struct OrbxTileDesc {
   int32_t l, tx, ty, f;
@@ -92,6 +92,14 @@ static_assert(sizeof(OrbxTileDesc) == 64, "one 64-byte scalar load per workgroup
 struct OrbxResizeTap {
   int32_t ofs;     // source index (clamped)
   int16_t c0, c1;  // weights of src[ofs], src[ofs+1]; c0+c1 ~ 2048
+};
+
+// the levels whose lower rows the second pass of the top-rows-first pipeline may skip (orbx_api.cpp, enqueue_batch)
+struct OrbxTopLevels {
+  int32_t n;
+  int32_t stat_index[ORBX_MAX_LEVELS];  // first tile-row statistic of the level
+  int32_t rows[ORBX_MAX_LEVELS];        // FAST tile rows of the first pass
+  int32_t cap[ORBX_MAX_LEVELS];
 };
 
 struct OrbxFastParams {
@@ -159,7 +167,8 @@ hipError_t orbx_launch_blur3(hipStream_t s, const OrbxTileDesc* d_tiles, int n_t
 hipError_t orbx_launch_pyrblur(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int w0, int h0,
                                int n_frames, const uint8_t* d_in, int in_stride, size_t in_frame_stride,
                                const OrbxResizeTap* d_taps, uint8_t* d_dst, int group = 0,
-                               const unsigned long long* d_row_stat = nullptr, uint32_t* d_feedback = nullptr);
+                               const unsigned long long* d_row_stat = nullptr, uint32_t* d_feedback = nullptr,
+                               const OrbxTopLevels* top = nullptr);
 // d_tiles: n_tiles OrbxTileDesc in band-major order (orbx_api.cpp: build_fast_tiles, tile height
 // orbx_fast3_tile_h(fp.nms_radius)); d_scores: optional dense u16 score map of ONE frame (stage operator)
 hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int n_frames,
