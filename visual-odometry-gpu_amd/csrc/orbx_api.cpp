@@ -161,8 +161,8 @@ struct orbx_ctx {
   int fast_early = 1;
   int fuse = 1;  // pyramid + blur in one kernel when blur runs on every level (orbx_set_fused_pyramid_blur)
   // Top-rows-first pipeline (enqueue_batch): 0 never, 1 whenever eligible, 2 adaptive -- the second pass
-  // counts the (frame, level)s it skipped / had to produce (d_feedback, running totals, copied to the pinned
-  // h_feedback at the end of every two-pass batch and read WITHOUT waiting at the start of later ones); while
+  // counts the (frame, level)s it skipped / had to produce (d_feedback, running totals, written to the pinned
+  // h_feedback by the last kernel of every two-pass batch and read WITHOUT waiting at the start of later ones); while
   // fewer than a quarter are skipped the batches run in one pass, and every 128th one probes again.
   int top_mode = 2;
   bool top_on = true;          // the adaptive verdict
@@ -778,9 +778,13 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
     if (tm == 1 || (tm == 2 && roofline_edge)) return hipEventRecord(evs[slot], s);
     return hipSuccess;
   };
-  // tile-row statistics of the FAST early exit: zeroed up front so that the events
-  // around the FAST stage bracket the kernel alone
-  HIPCHK(c, hipMemsetAsync(c->d_row_stat, 0, (size_t)n * ORBX_FAST_STAT_WORDS * 8, s));
+  // tile-row statistics of the FAST early exit: zeroed up front so that the events around the FAST stage bracket
+  // the kernel alone -- except in the top-rows-first pipeline (decided below; the same test here), whose first
+  // pyramid pass clears them itself: a memset node less per batch
+  const bool small0 = (long long)n * c->pyrblur_tiles_count < 4096;
+  const bool two_pass0 = fused_pyrblur(c) && !small0 && fast_early_on(c) && top_rows_wanted(c) && c->pyrblur_rest_count > 0 &&
+                         c->bm_fast.nbands > top_rows_env();
+  if (!two_pass0) HIPCHK(c, hipMemsetAsync(c->d_row_stat, 0, (size_t)n * ORBX_FAST_STAT_WORDS * 8, s));
   HIPCHK(c, mark(0, false));
   OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2};
   bool two_pass = false;
@@ -810,7 +814,8 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
     } else {
       const int first_tiles = c->bm_fast.band_begin[top_rows_env()];
       HIPCHK(c, orbx_launch_pyrblur(s, c->d_tiles_pyrblur_top, c->pyrblur_top_count, P.frame_bytes, P.w0, P.h0, n, d_frames,
-                                    row_stride, frame_stride, c->d_taps, c->d_pyr_blur, pyr_group_env()));
+                                    row_stride, frame_stride, c->d_taps, c->d_pyr_blur, pyr_group_env(), nullptr, nullptr, nullptr,
+                                    c->d_row_stat));
       HIPCHK(c, mark(ORBX_NUM_STAGE_TIMES + 1, true));
       HIPCHK(c, orbx_launch_fast_nms(s, c->d_tiles_fast, first_tiles, n, final_pyr(c), P.frame_bytes, P.mask_words, fp,
                                      c->d_mask, nullptr, c->d_row_stat));
@@ -821,7 +826,6 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
       HIPCHK(c, mark(2, true));
       HIPCHK(c, orbx_launch_fast_nms(s, c->d_tiles_fast + first_tiles, c->fast_tiles_count - first_tiles, n, final_pyr(c),
                                      P.frame_bytes, P.mask_words, fp, c->d_mask, nullptr, c->d_row_stat, 4));
-      HIPCHK(c, hipMemcpyAsync(const_cast<uint32_t*>(c->h_feedback), c->d_feedback, 8, hipMemcpyDeviceToHost, s));
     }
   } else {
     HIPCHK(c, launch_pyramid_auto(c, s, n, d_frames, row_stride, frame_stride));
@@ -856,7 +860,8 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
                                  (int32_t*)(c->d_out + o.counts), (orbx_keypoint*)(c->d_out + o.lkp),
                                  (float*)(c->d_out + o.resp), (int32_t*)(c->d_out + o.level),
                                  (orbx_keypoint*)(c->d_out + o.kp), (float*)(c->d_out + o.angle),
-                                 (orbx_descriptor*)(c->d_out + o.desc)));
+                                 (orbx_descriptor*)(c->d_out + o.desc), two_pass ? c->d_feedback : nullptr,
+                                 two_pass ? const_cast<uint32_t*>(c->h_feedback) : nullptr));
   HIPCHK(c, mark(7, false));
   return ORBX_OK;
 }

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 8) void k_pyrblur(const OrbxTileDesc* __restri
                                                  size_t in_frame_stride, const OrbxResizeTap* __restrict__ taps,
                                                  uint8_t* __restrict__ dst, int group, int n_frames,
                                                  const u64* __restrict__ row_stat, uint32_t* __restrict__ feedback,
-                                                 OrbxTopLevels top) {
+                                                 OrbxTopLevels top, u64* __restrict__ zero_stat) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int wg = blockIdx.x, f = blockIdx.y;
   if (group) {
@@ -382,6 +382,10 @@ __global__ __launch_bounds__(256, 8) void k_pyrblur(const OrbxTileDesc* __restri
     f = g * group + (r - wg * gsize);
     if (wg >= nwg) return;  // (the last, smaller group)
   }
+  // First pass of the top-rows-first pipeline: the first workgroup of a frame clears the frame's FAST early-exit
+  // statistics (the FAST launch that fills them comes after this kernel): a memset node less per batch
+  if (zero_stat && wg == 0)
+    for (int i = threadIdx.x; i < ORBX_FAST_STAT_WORDS; i += 256) zero_stat[(size_t)f * ORBX_FAST_STAT_WORDS + i] = 0ull;
   const int ti = wg * 4 + wave;
   if (ti >= n_tiles) return;  // whole wave
   const OrbxTileDesc d = tiles[ti];
@@ -521,14 +525,15 @@ hipError_t orbx_launch_blur3(hipStream_t s, const OrbxTileDesc* d_tiles, int n_t
 hipError_t orbx_launch_pyrblur(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int w0, int h0,
                                int n_frames, const uint8_t* d_in, int in_stride, size_t in_frame_stride,
                                const OrbxResizeTap* d_taps, uint8_t* d_dst, int group,
-                               const unsigned long long* d_row_stat, uint32_t* d_feedback, const OrbxTopLevels* top) {
+                               const unsigned long long* d_row_stat, uint32_t* d_feedback, const OrbxTopLevels* top,
+                               unsigned long long* d_zero_stat) {
   OrbxTopLevels tl{};
   if (top) tl = *top;
   if (n_tiles <= 0 || n_frames <= 0) return hipSuccess;
   if (group > 0) {
     const int nwg = (n_tiles + 3) / 4, ngroups = (n_frames + group - 1) / group;
     hipLaunchKernelGGL(k_pyrblur, dim3((unsigned)(ngroups * group * nwg)), dim3(256), 0, s, d_tiles, n_tiles, frame_bytes,
-                       w0, h0, d_in, in_stride, in_frame_stride, d_taps, d_dst, group, n_frames, d_row_stat, d_feedback, tl);
+                       w0, h0, d_in, in_stride, in_frame_stride, d_taps, d_dst, group, n_frames, d_row_stat, d_feedback, tl, d_zero_stat);
     return hipGetLastError();
   }
   // Workgroups are dealt round-robin over the 8 XCDs in linear order (x fastest).  With a grid.x that
@@ -538,6 +543,6 @@ hipError_t orbx_launch_pyrblur(hipStream_t s, const OrbxTileDesc* d_tiles, int n
   // the assignment from frame to frame; the padding workgroup exits at once.
   dim3 grid(((n_tiles + 3) / 4) | 1, n_frames);
   hipLaunchKernelGGL(k_pyrblur, grid, dim3(256), 0, s, d_tiles, n_tiles, frame_bytes, w0, h0, d_in, in_stride,
-                     in_frame_stride, d_taps, d_dst, 0, n_frames, d_row_stat, d_feedback, tl);
+                     in_frame_stride, d_taps, d_dst, 0, n_frames, d_row_stat, d_feedback, tl, d_zero_stat);
   return hipGetLastError();
 }

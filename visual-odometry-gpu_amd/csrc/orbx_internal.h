@@ -168,7 +168,7 @@ hipError_t orbx_launch_pyrblur(hipStream_t s, const OrbxTileDesc* d_tiles, int n
                                int n_frames, const uint8_t* d_in, int in_stride, size_t in_frame_stride,
                                const OrbxResizeTap* d_taps, uint8_t* d_dst, int group = 0,
                                const unsigned long long* d_row_stat = nullptr, uint32_t* d_feedback = nullptr,
-                               const OrbxTopLevels* top = nullptr);
+                               const OrbxTopLevels* top = nullptr, unsigned long long* d_zero_stat = nullptr);
 // d_tiles: n_tiles OrbxTileDesc in band-major order (orbx_api.cpp: build_fast_tiles, tile height
 // orbx_fast3_tile_h(fp.nms_radius)); d_scores: optional dense u16 score map of ONE frame (stage operator)
 hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int n_frames,
@@ -197,7 +197,8 @@ hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frame
                                 int patch_size, const int32_t* d_sel_count, const orbx_keypoint* d_sel_lkp,
                                 const float* d_sel_resp, int32_t* d_out_count, orbx_keypoint* d_out_lkp,
                                 float* d_out_resp, int32_t* d_out_level, orbx_keypoint* d_out_kp, float* d_out_angle,
-                                orbx_descriptor* d_out_desc);
+                                orbx_descriptor* d_out_desc, const uint32_t* d_feedback = nullptr,
+                                uint32_t* h_feedback = nullptr);
 
 // stage-level helpers on plain (single-image, arbitrary pitch) buffers
 hipError_t orbx_launch_describe_flat(hipStream_t s, const uint8_t* d_img, int w, int h, int pitch,

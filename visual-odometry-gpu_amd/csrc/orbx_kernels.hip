@@ -1262,7 +1262,8 @@ __global__ __launch_bounds__(64 * DESC_NW, DESC_OCC) void k_describe2(OrbxPlan p
                                                    int32_t* __restrict__ out_level,
                                                    orbx_keypoint* __restrict__ out_kp,
                                                    float* __restrict__ out_angle,
-                                                   orbx_descriptor* __restrict__ out_desc) {
+                                                   orbx_descriptor* __restrict__ out_desc,
+                                                   const uint32_t* __restrict__ feedback, uint32_t* __restrict__ feedback_host) {
   constexpr int DESC_KPB = DESC_NW * DESC_KPW;
   static_assert(2 * DESC_KPB <= 64 * DESC_NW, "trig: two threads per keypoint");
   __shared__ __attribute__((aligned(16))) DescLds2 s_lds[DESC_NW];
@@ -1281,6 +1282,9 @@ __global__ __launch_bounds__(64 * DESC_NW, DESC_OCC) void k_describe2(OrbxPlan p
   const int lvl_end = wave_scan_incl(lvl_cnt);  // slots of levels 0..lane
   const int count = __builtin_amdgcn_readlane(lvl_end, 63);
   if (grp == 0 && tid == 0) out_count[f] = count;
+  // (last kernel of a batch: the running totals of the top-rows-first pipeline's second pass go to the host's pinned
+  // word pair, which the host reads without waiting when it enqueues later batches -- a copy node less per batch)
+  if (feedback_host && grp == 0 && f == 0 && tid < 2) feedback_host[tid] = feedback[tid];
   const int slot0 = grp * DESC_KPB;
   if (slot0 >= count) return;  // whole workgroup
   DescLds2& lds = s_lds[wave];
@@ -1697,21 +1701,23 @@ hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frame
                                 int patch_size, const int32_t* d_sel_count, const orbx_keypoint* d_sel_lkp,
                                 const float* d_sel_resp, int32_t* d_out_count, orbx_keypoint* d_out_lkp,
                                 float* d_out_resp, int32_t* d_out_level, orbx_keypoint* d_out_kp, float* d_out_angle,
-                                orbx_descriptor* d_out_desc) {
+                                orbx_descriptor* d_out_desc, const uint32_t* d_feedback, uint32_t* h_feedback) {
   if (plan.out_cap <= 0) return hipSuccess;
   // few keypoints in flight (single frames, small batches): one keypoint per wave, four times the
   // workgroups, a quarter of the serial work per wave; else four per wave
   if ((long long)plan.out_cap * n_frames <= 8192) {
     dim3 grid(n_frames, (plan.out_cap + 3) / 4);
     hipLaunchKernelGGL((k_describe2<1, 4, 1>), grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
-                       d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc);
+                       d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc, d_feedback,
+                       h_feedback);
   } else {
     // Four waves of four keypoints, registers capped for 7 waves per SIMD (5.1 KB of LDS per wave: 7 workgroups
     // per CU).  Measured per 256 frames: 8-wave workgroups at 6 waves per SIMD (the trig -- two threads per
     // keypoint -- fills a wave: -1.8 % instructions) 203 us, 7-wave workgroups 221 us, this 197 us.
     dim3 grid(n_frames, (plan.out_cap + 15) / 16);
     hipLaunchKernelGGL((k_describe2<4, 4, 7>), grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
-                       d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc);
+                       d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc, d_feedback,
+                       h_feedback);
   }
   return ORBX_LAUNCH_CHECK();
 }
