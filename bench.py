@@ -215,6 +215,9 @@ def main():
                     help="run the TIMED region with the FAST early exit off (for rocprofv3 runs of the full-work kernel)")
     ap.add_argument("--unfused", action="store_true",
                     help="run the TIMED region with separate pyramid and blur kernels (for rocprofv3 runs of each kernel)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="timed region without orbx_set_pipelined_batches (consecutive batches then run one after the other "
+                         "on one stream); implied by --only-timed, whose rocprofv3 kernel durations must not overlap")
     ap.add_argument("--pmc-file", default=PMC_FILE,
                     help="per-kernel counters from separate rocprofv3 --pmc passes of THIS build (tools/pmc_collect.sh)")
     args = ap.parse_args()
@@ -305,10 +308,20 @@ def main():
         submit(i)
         ctx.wait()
 
-    # ---- timed region: exactly `steps` steps, enqueued back to back on the context's stream, one wait at
-    # the end.  HIP events on that stream bracket only the two roofline kernels, blur and fast+nms (event
-    # records around all seven stages would inflate `value` by ~7 %).
-    ctx.enable_stage_timing(2)
+    # ---- timed region: exactly `steps` steps, enqueued back to back, one wait at the end.  Production shape:
+    # pipelined batches (orbx_set_pipelined_batches: consecutive batches alternate between two lanes -- own stream,
+    # own pools -- and overlap), one hipGraph launch per batch, no event records.  With --only-timed / --no-pipeline:
+    # one stream, and HIP events on it bracket the two roofline stages (kernel durations then do not overlap, which
+    # the rocprofv3 collection needs).
+    pipelined = not (args.only_timed or args.no_pipeline)
+    if pipelined:
+        ctx.set_pipelined_batches(True)
+        for i in range(2):  # (both lanes' graphs captured before the clock starts)
+            submit(i)
+        ctx.wait()
+        ctx.enable_stage_timing(0)
+    else:
+        ctx.enable_stage_timing(2)
     barrier()
     t0 = time.perf_counter()
     nframes = 0
@@ -321,12 +334,15 @@ def main():
     nframes_all = grp.sum_int(nframes)
     fast_tiles = ctx.fast_tile_counts()  # (did the full work, all) of the last timed step
     pyr_done = ctx.pyramid_pixel_counts()  # (pyramid pixels produced, all) of the last timed step
-    nread = min(steps, 64)
     roof_ms = {"blur": 0.0, "fast_nms": 0.0}
-    for back in range(nread):
-        lt = ctx.last_stage_times(back)
-        for k in roof_ms:
-            roof_ms[k] += lt[k] / nread
+    if pipelined:
+        ctx.set_pipelined_batches(False)  # the per-stage passes below run one batch at a time
+    else:
+        nread = min(steps, 64)
+        for back in range(nread):
+            lt = ctx.last_stage_times(back)
+            for k in roof_ms:
+                roof_ms[k] += lt[k] / nread
 
     # ---- stream mode: the checksum of the whole pass (independent of the sharding)
     stream_info = None
@@ -361,6 +377,8 @@ def main():
 
     zero = {k: 0.0 for k in pkg.orbx.STAGE_NAMES}
     stage_ms = breakdown() if not args.only_timed else dict(zero)
+    if pipelined:  # (the timed region carried no events: the roofline stages' times come from the per-stage pass)
+        roof_ms = {"blur": stage_ms["blur"], "fast_nms": stage_ms["fast_nms"]}
     full_ms, full_tiles = dict(stage_ms), fast_tiles
     if not args.only_timed and not args.full_work:
         ctx.set_fast_early_exit(False)
@@ -391,7 +409,7 @@ def main():
     # the context's copy stream while batch i+1 runs (orbx_batch_prefetch / orbx_batch_fetch_previous)
     fps_d2h = fps_d2h_blocking = None
     if not args.only_timed:
-        nd = max(steps, 10)
+        nd = max(steps, 10)  # (one lane: at ~400 k frames/s the 59 KB of results per frame saturate the host link either way)
         submit(0)
         ctx.batch_prefetch()
         t1 = time.perf_counter()
@@ -554,7 +572,7 @@ def main():
             "config": {"workload": wl, "frames_per_step_per_gpu": B, "distinct_resident_batches": len(batches),
                        "sharding": "frame-parallel, no data-path collective",
                        "fast_early_exit": not args.full_work, "pyramid_blur_fused": not args.unfused,
-                       "pyramid_top_rows_first": bool(pyr_done[0] < pyr_done[1])},
+                       "pyramid_top_rows_first": bool(pyr_done[0] < pyr_done[1]), "pipelined_batches": pipelined},
             "roofline": {"bound": "hbm", "kernel": "k_blur3 (stand-alone)" if dom == "blur_alone" else "k_fast3 (every tile working)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": kern.get(dom, {}).get("hbm_traffic_bytes_per_launch"),

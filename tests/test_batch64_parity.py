@@ -227,3 +227,52 @@ def test_top_rows_first_adapts_to_the_stream(pkg, frames, oracle_results):
             compare(c.batch_fetch(0, B, cap), oracle_results, cap)
             done, total = c.pyramid_pixel_counts()
         assert done < 0.7 * total
+
+
+def test_pipelined_batches_overlap_without_changing_results(pkg, frames, oracle_results):
+    """orbx_set_pipelined_batches: consecutive device-resident batches alternate between two lanes (own stream, own
+    pools) and overlap on the GPU.  A stream of batches with three different inputs, results read from the pinned
+    mirror of the PREVIOUS batch while the next one runs (the bench's streaming-consumer loop), must equal what the
+    same batches give one at a time; entry points outside the streaming set may be called in between."""
+    import torch
+
+    inputs = [frames, np.ascontiguousarray(frames[::-1]), np.ascontiguousarray(np.roll(frames, (5, 9), (1, 2)))]
+    dev = [torch.from_numpy(a).cuda() for a in inputs]
+    torch.cuda.synchronize()
+    p = pkg.default_params("gpu", max_width=W, max_height=H, max_batch=B, **PK)
+    shard = pkg.shard
+    with pkg.Context(p) as c:
+        cap = c.plan(W, H)["out_capacity"]
+        want = []
+        for d in dev:  # one at a time
+            c.batch_device(d.data_ptr(), B, W, H)
+            r = c.batch_fetch(0, B, cap)
+            want.append((int(r["counts"].sum()), shard.descriptor_checksum(r["counts"], r["desc"])))
+        c.set_pipelined_batches(True)
+        order = [0, 1, 2, 0, 2, 1, 1, 0, 2, 2]
+        got = []
+        c.batch_device(dev[order[0]].data_ptr(), B, W, H)
+        c.batch_prefetch()
+        for k in order[1:]:
+            c.batch_device(dev[k].data_ptr(), B, W, H)
+            hv = c.batch_host_view(previous=True)  # the batch before, zero-copy from its pinned mirror
+            got.append((int(hv["counts"].sum()), shard.descriptor_checksum(hv["counts"], hv["desc"])))
+            c.batch_prefetch()
+        r = c.batch_fetch(0, B, cap)  # the last one (waits for its lane)
+        got.append((int(r["counts"].sum()), shard.descriptor_checksum(r["counts"], r["desc"])))
+        assert got == [want[k] for k in order]
+        # the first input against the oracle as well, through the pipelined path
+        c.batch_device(dev[1].data_ptr(), B, W, H)
+        c.batch_device(dev[0].data_ptr(), B, W, H)
+        compare(c.batch_fetch(0, B, cap), oracle_results, cap)
+        # entry points outside the streaming set wait for both lanes: a stage operator and the tile counts in between
+        c.batch_device(dev[2].data_ptr(), B, W, H)
+        c.batch_device(dev[1].data_ptr(), B, W, H)
+        kps, total = c.fast(inputs[0][0], 20, 9, 3, 3000)
+        assert total > 0
+        worked, alltiles = c.fast_tile_counts()
+        assert 0 < worked <= alltiles
+        c.wait()
+        c.set_pipelined_batches(False)
+        c.batch_device(dev[0].data_ptr(), B, W, H)
+        compare(c.batch_fetch(0, B, cap), oracle_results, cap)

@@ -142,6 +142,22 @@ struct orbx_ctx {
   uint8_t* h_out = nullptr;  // pinned mirror
   OutLayout out_layout{};
   int out_cap = 0;  // slot capacity of the pool (plan_max.out_cap)
+  // Pipelined batches (orbx_set_pipelined_batches): two LANES, each with its own stream and its own working pools
+  // (pyramids, mask, statistics, candidates); consecutive device-resident batches alternate between them -- batch
+  // k uses lane k & 1 = its result block -- so the kernels of one batch overlap the tails and the nearly empty
+  // launches of the other.  lane_pool[0] / lane_stream[0] are the context's own pools / stream; the d_* members
+  // above always point at the pools of the most recent batch's lane.
+  struct LanePool {
+    uint8_t *d_pyr = nullptr, *d_pyr_blur = nullptr;
+    unsigned long long *d_mask = nullptr, *d_row_stat = nullptr;
+    orbx_keypoint* d_cand = nullptr;
+    int32_t *d_cand_count = nullptr, *d_cand_total = nullptr, *d_lcount = nullptr;
+    float *d_resp = nullptr, *d_lresp = nullptr;
+    uint32_t* d_lcand = nullptr;
+  };
+  LanePool lane_pool[2];
+  hipStream_t lane_stream[2] = {nullptr, nullptr};
+  bool pipelined = false;
   int last_n = 0;
   bool last_two_pass = false;  // the last batch built its pyramid top rows first (enqueue_batch)
   hipStream_t last_stream = nullptr;
@@ -614,6 +630,31 @@ int validate_params(const orbx_params& p, std::string* why) {
   return ORBX_OK;
 }
 
+// the working pools of lane k become the context's current ones
+void use_lane(orbx_ctx* c, int k) {
+  const orbx_ctx::LanePool& L = c->lane_pool[k];
+  c->d_pyr = L.d_pyr;
+  c->d_pyr_blur = L.d_pyr_blur;
+  c->d_mask = L.d_mask;
+  c->d_row_stat = L.d_row_stat;
+  c->d_cand = L.d_cand;
+  c->d_cand_count = L.d_cand_count;
+  c->d_cand_total = L.d_cand_total;
+  c->d_resp = L.d_resp;
+  c->d_lcand = L.d_lcand;
+  c->d_lresp = L.d_lresp;
+  c->d_lcount = L.d_lcount;
+}
+// everything either lane has in flight has finished
+hipError_t lanes_sync(orbx_ctx* c) {
+  for (hipStream_t s : c->lane_stream)
+    if (s) {
+      const hipError_t e = hipStreamSynchronize(s);
+      if (e != hipSuccess) return e;
+    }
+  return hipSuccess;
+}
+
 int set_plan(orbx_ctx* c, int w, int h) {
   if (w == c->plan_w && h == c->plan_h) return ORBX_OK;
   if (w < 8 || h < 8 || w > c->p.max_width || h > c->p.max_height)
@@ -626,6 +667,7 @@ int set_plan(orbx_ctx* c, int w, int h) {
   if (c->h_taps.size() > c->taps_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "resize table exceeds pool");
   // the table may still be in use by an in-flight batch of the previous size
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, lanes_sync(c));
   if (c->last_stream && c->last_stream != c->stream) HIPCHK(c, hipStreamSynchronize(c->last_stream));
   HIPCHK(c, hipMemcpy(c->d_taps, c->h_taps.data(), c->h_taps.size() * sizeof(OrbxResizeTap),
                       hipMemcpyHostToDevice));
@@ -634,6 +676,9 @@ int set_plan(orbx_ctx* c, int w, int h) {
   // padding bytes of a level being zero (BRIEF's zero-extension), and another frame size re-uses the pool
   if (c->d_pyr_blur) {  // (on the context's stream, and waited for: batches may run on a caller's stream)
     HIPCHK(c, hipMemsetAsync(c->d_pyr_blur, 0, (size_t)c->p.max_batch * (size_t)c->plan_max.frame_bytes, c->stream));
+    const orbx_ctx::LanePool& other = c->lane_pool[c->d_pyr_blur == c->lane_pool[0].d_pyr_blur ? 1 : 0];
+    if (other.d_pyr_blur)  // the other lane's pool as well
+      HIPCHK(c, hipMemsetAsync(other.d_pyr_blur, 0, (size_t)c->p.max_batch * (size_t)c->plan_max.frame_bytes, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   make_tilemap(plan, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &c->tm_blur);
@@ -876,10 +921,22 @@ void drop_graph(orbx_ctx* c, int i) {
 }
 
 int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row_stride, size_t frame_stride,
-              hipStream_t s) {
-  // the pools (pyramids, mask, result block) are reused by every batch: a batch still in
-  // flight on a DIFFERENT stream must have finished before this one may touch them
-  if (c->last_stream && c->last_stream != s) HIPCHK(c, hipStreamSynchronize(c->last_stream));
+              hipStream_t s, bool may_pipeline = false) {
+  // Pipelined mode: a device-resident batch on the context's stream goes to the lane of its result block -- own
+  // pools, own stream, so nothing of the other lane's batch in flight is touched.  (The plan's tables are shared:
+  // set_plan waits for both lanes before it changes them.)
+  const bool lanes = may_pipeline && c->pipelined && s == c->stream && w == c->plan_w && h == c->plan_h;
+  if (lanes) {
+    const int lane = c->blk ^ 1;
+    use_lane(c, lane);
+    s = c->lane_stream[lane];
+  } else {
+    if (c->lane_stream[1]) HIPCHK(c, lanes_sync(c));
+    use_lane(c, 0);
+    // the pools (pyramids, mask, result block) are reused by every batch: a batch still in
+    // flight on a DIFFERENT stream must have finished before this one may touch them
+    if (c->last_stream && c->last_stream != s) HIPCHK(c, hipStreamSynchronize(c->last_stream));
+  }
   int st = set_plan(c, w, h);
   if (st != ORBX_OK) return st;
   top_rows_update(c);
@@ -896,7 +953,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   }();
   const int tm = c->timing;
   if (use_graph && tm == 0) {
-    const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, (fast_early_on(c) ? 1 : 0) | (fused_pyrblur(c) ? 2 : 0) | (top_rows_wanted(c) ? 4 : 0),
+    const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, (fast_early_on(c) ? 1 : 0) | (fused_pyrblur(c) ? 2 : 0) | (top_rows_wanted(c) ? 4 : 0) | (lanes ? 8 : 0),
                            c->plan_serial, blk};
     int gi = -1;
     for (int i = 0; i < orbx_ctx::kGraphs; i++)
@@ -1048,6 +1105,17 @@ void orbx_destroy(orbx_ctx* c) {
   DeviceGuard _dg(c);
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->lane_stream[1]) {  // the second lane of the pipelined mode
+    (void)hipStreamSynchronize(c->lane_stream[1]);
+    use_lane(c, 0);  // (the list below frees the context's own pools)
+    const orbx_ctx::LanePool& L = c->lane_pool[1];
+    void* lb[] = {L.d_pyr, L.d_pyr_blur, L.d_mask, L.d_row_stat, L.d_cand, L.d_cand_count, L.d_cand_total, L.d_resp,
+                  L.d_lcand, L.d_lresp, L.d_lcount};
+    for (void* b : lb)
+      if (b) (void)hipFree(b);
+    (void)hipStreamDestroy(c->lane_stream[1]);
+    c->lane_stream[1] = nullptr;
+  }
   for (int i = 0; i < orbx_ctx::kGraphs; i++) drop_graph(c, i);
   void* bufs[] = {c->d_in,   c->d_pyr,  c->d_pyr_blur, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total,
                   c->d_resp, c->d_taps, c->d_gauss,    c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur, c->d_tiles_pyr2, c->d_tiles_pyrblur, c->d_tiles_pyrblur_small,
@@ -1202,6 +1270,21 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
     c->h_out = c->h_outb[0];
   }
 #undef CREATE_CHK
+  {  // lane 0 of the pipelined mode = the context's own pools and stream
+    orbx_ctx::LanePool& L = c->lane_pool[0];
+    L.d_pyr = c->d_pyr;
+    L.d_pyr_blur = c->d_pyr_blur;
+    L.d_mask = c->d_mask;
+    L.d_row_stat = c->d_row_stat;
+    L.d_cand = c->d_cand;
+    L.d_cand_count = c->d_cand_count;
+    L.d_cand_total = c->d_cand_total;
+    L.d_resp = c->d_resp;
+    L.d_lcand = c->d_lcand;
+    L.d_lresp = c->d_lresp;
+    L.d_lcount = c->d_lcount;
+    c->lane_stream[0] = c->stream;
+  }
   *out = c;
   return ORBX_OK;
 }
@@ -1235,7 +1318,7 @@ int orbx_detect_and_compute_batch_device(orbx_ctx* c, const void* d_frames, int 
   if (frame_stride < (size_t)row_stride * (size_t)(height - 1) + (size_t)width)
     return fail(c, ORBX_ERR_INVALID_ARG, "frame_stride smaller than a frame");
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-  return run_batch(c, (const uint8_t*)d_frames, n, width, height, row_stride, frame_stride, s);
+  return run_batch(c, (const uint8_t*)d_frames, n, width, height, row_stride, frame_stride, s, true);
 }
 
 int orbx_detect_and_compute_batch_host(orbx_ctx* c, const uint8_t* frames, int n, int width, int height,
@@ -1262,6 +1345,37 @@ int orbx_wait(orbx_ctx* c) {
   DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   HIPCHK(c, hipStreamSynchronize(c->last_stream ? c->last_stream : c->stream));
+  HIPCHK(c, lanes_sync(c));
+  return ORBX_OK;
+}
+
+int orbx_set_pipelined_batches(orbx_ctx* c, int enable) {
+  DeviceGuard _dg(c);
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  if (c->last_stream) HIPCHK(c, hipStreamSynchronize(c->last_stream));
+  HIPCHK(c, lanes_sync(c));
+  if (enable && !c->lane_stream[1]) {  // the second lane: a stream and a second set of working pools
+    const orbx_params* p = &c->p;
+    const OrbxPlan& M = c->plan_max;
+    const size_t B = (size_t)p->max_batch;
+    orbx_ctx::LanePool& L = c->lane_pool[1];
+    HIPCHK(c, hipMalloc((void**)&L.d_pyr, B * (size_t)M.frame_bytes + 256));
+    if (p->blur_levels != ORBX_BLUR_NONE) {
+      HIPCHK(c, hipMalloc((void**)&L.d_pyr_blur, B * (size_t)M.frame_bytes + 256));
+      HIPCHK(c, hipMemset(L.d_pyr_blur, 0, B * (size_t)M.frame_bytes));  // (the padding bytes of a level stay zero)
+    }
+    HIPCHK(c, hipMalloc((void**)&L.d_mask, B * (size_t)M.mask_words * 8 + 256));
+    HIPCHK(c, hipMalloc((void**)&L.d_row_stat, B * ORBX_FAST_STAT_WORDS * 8));
+    HIPCHK(c, hipMalloc((void**)&L.d_cand, B * (size_t)std::max(M.cand_total, 1) * sizeof(orbx_keypoint)));
+    HIPCHK(c, hipMalloc((void**)&L.d_cand_count, B * ORBX_MAX_LEVELS * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc((void**)&L.d_cand_total, B * ORBX_MAX_LEVELS * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc((void**)&L.d_resp, B * (size_t)std::max(M.cand_total, 1) * sizeof(float)));
+    HIPCHK(c, hipMalloc((void**)&L.d_lcand, B * (size_t)std::max(M.cand_total, 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&L.d_lresp, B * (size_t)std::max(M.cand_total, 1) * sizeof(float)));
+    HIPCHK(c, hipMalloc((void**)&L.d_lcount, B * ORBX_MAX_LEVELS * sizeof(int32_t)));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->lane_stream[1], hipStreamNonBlocking));
+  }
+  c->pipelined = enable != 0;
   return ORBX_OK;
 }
 
@@ -1521,6 +1635,7 @@ int orbx_bench_stage(orbx_ctx* c, int n_frames, int stage, int reps, float* avg_
   hipStream_t s = c->stream;
   OrbxFastParams fp{c->p.threshold, c->p.n, c->p.nms_window / 2};
   HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, lanes_sync(c));  // (the last batch may have run on the other lane's stream)
   HIPCHK(c, hipEventRecord(c->ev[0], s));
   for (int i = 0; i < reps; i++) {
     switch (stage) {
@@ -1826,6 +1941,7 @@ int orbx_build_pyramid_level(orbx_ctx* c, const uint8_t* image, int width, int h
   if (level < 0 || level >= c->p.nlevels || !dst) return fail(c, ORBX_ERR_INVALID_ARG, "level out of range / dst NULL");
   if ((st = set_plan(c, width, height)) != ORBX_OK) return st;
   const OrbxPlan& P = c->plan;
+  HIPCHK(c, lanes_sync(c));
   HIPCHK(c, hipMemcpy2DAsync(c->d_in, width, image, stride, width, height, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, launch_pyramid_auto(c, c->stream, 1, c->d_in, width, (size_t)width * height));
   if (blur_enabled(c))

@@ -30,7 +30,7 @@ EXPORTS = [
     "orbx_wait", "orbx_batch_results_device", "orbx_batch_results_host", "orbx_batch_fetch", "orbx_batch_prefetch",
     "orbx_batch_fetch_previous", "orbx_enable_stage_timing",
     "orbx_last_stage_times", "orbx_stage_times_history", "orbx_bench_stage", "orbx_set_fast_early_exit",
-    "orbx_set_fused_pyramid_blur", "orbx_set_top_rows_first", "orbx_fast_tile_counts", "orbx_pyramid_pixel_counts", "orbx_lk_track", "orbx_lk_pyramid_levels", "orbx_fast_score", "orbx_nms", "orbx_fast",
+    "orbx_set_fused_pyramid_blur", "orbx_set_top_rows_first", "orbx_set_pipelined_batches", "orbx_fast_tile_counts", "orbx_pyramid_pixel_counts", "orbx_lk_track", "orbx_lk_pyramid_levels", "orbx_fast_score", "orbx_nms", "orbx_fast",
     "orbx_orientations", "orbx_brief", "orbx_harris", "orbx_blur5_sep", "orbx_blur5_273", "orbx_conv2d",
     "orbx_gaussian_blur_conv", "orbx_gaussian_kernel", "orbx_sobel", "orbx_build_pyramid_level",
     "orbx_select_top", "orbx_knn2", "orbx_match_ratio", "orbx_batch_match_consecutive", "orbx_batch_match_fetch",
@@ -283,6 +283,10 @@ class Context:
 
     def set_fused_pyramid_blur(self, on=True):
         self._chk(self._lib.orbx_set_fused_pyramid_blur(self._h, 1 if on else 0))
+
+    def set_pipelined_batches(self, on=True):
+        """Consecutive batch_device calls alternate between two lanes (own stream, own pools) and overlap."""
+        self._chk(self._lib.orbx_set_pipelined_batches(self._h, 1 if on else 0))
 
     def set_top_rows_first(self, mode=2):
         """0: one pass, 1: the pyramid top rows first whenever eligible, 2: adaptive (default)."""
