@@ -78,10 +78,26 @@ def main():
                 cap = max(c.plan(w, h)["out_capacity"], 1)
                 c.set_fast_early_exit(bool(rng.integers(0, 2)))
                 c.set_fused_pyramid_blur(bool(rng.integers(0, 2)))
-                if big:  # another batch first: rows a skipped strip leaves in the pool must never be read
-                    c.batch_host(np.ascontiguousarray(imgs[::-1]))
-                c.batch_host(imgs)
-                r = c.batch_fetch(0, B, cap)
+                if big and rng.random() < 0.5:
+                    # device-resident batches through the two lanes of the pipelined mode, back to back: the
+                    # reversed batch on one lane, the real one on the other
+                    import torch
+                    d_rev = torch.from_numpy(np.ascontiguousarray(imgs[::-1])).cuda()
+                    d_img = torch.from_numpy(imgs).cuda()
+                    torch.cuda.synchronize()
+                    c.batch_host(imgs[:1])  # (sets the plan: the lanes engage for an unchanged frame size)
+                    c.set_pipelined_batches(True)
+                    c.batch_device(d_rev.data_ptr(), B, w, h)
+                    c.batch_device(d_img.data_ptr(), B, w, h)
+                    c.batch_device(d_rev.data_ptr(), B, w, h)
+                    c.batch_device(d_img.data_ptr(), B, w, h)
+                    r = c.batch_fetch(0, B, cap)
+                    c.set_pipelined_batches(False)
+                else:
+                    if big:  # another batch first: rows a skipped strip leaves in the pool must never be read
+                        c.batch_host(np.ascontiguousarray(imgs[::-1]))
+                    c.batch_host(imgs)
+                    r = c.batch_fetch(0, B, cap)
                 single = c.detect_and_compute(imgs[0])
         except pkg.OrbxError as e:
             if e.status == pkg.orbx.ERR_UNSUPPORTED:
