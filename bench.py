@@ -12,7 +12,9 @@ patch 31, rotated BRIEF-256, 5x5 Gaussian blur on every level.  A "step" = one p
 path over one batch of --batch (default 256) synthetic frames that are already resident in HBM; the
 steps rotate over --rotate (default 2) DISTINCT resident batches, so the pools of a step (~0.9 GB) and
 its inputs lie far beyond the 256 MiB Infinity Cache: every kernel streams from and to HBM.  Results stay resident in HBM too
-(the D2H-inclusive rate is reported beside it as `fps_with_d2h`, it is never `value`).
+(the D2H-inclusive rate is reported beside it as `fps_with_d2h`, it is never `value`).  The timed region is the
+production shape: pipelined batches (orbx_set_pipelined_batches: two batches in flight on two lanes of the context),
+one hipGraph launch per batch; per-kernel figures come from passes that run one batch at a time.
 
 Frames are independent, so ranks shard the stream with NO data-path collective (weak scaling: every
 rank processes its own batches); torch.distributed (RCCL) is used only for the barrier, the
