@@ -175,6 +175,7 @@ struct orbx_ctx {
 
   int timing = 0;  // 0 off, 1 all stages, 2 blur + fast only
   int fast_early = 1;
+  int fast_impl = 4;  // 4: streaming FAST kernel (orbx_fast4.hip), 3: LDS tile kernel (ORBX_FAST_IMPL, read at creation)
   int fuse = 1;  // pyramid + blur in one kernel when blur runs on every level (orbx_set_fused_pyramid_blur)
   // Top-rows-first pipeline (enqueue_batch): 0 never, 1 whenever eligible, 2 adaptive -- the second pass
   // counts the (frame, level)s it skipped / had to produce (d_feedback, running totals, written to the pinned
@@ -286,12 +287,14 @@ void make_tilemap(const OrbxPlan& plan, int tw, int th, bool use_pitch, OrbxTile
 
 // band-major order of the FAST tiles (levels shrink with the level index, so the
 // levels that have a tile row b are always a prefix of the level list)
-int make_bandmap(const OrbxPlan& plan, int nms_radius, OrbxBandMap* bm, std::string* why) {
+// strips: the units of the streaming kernel of the whole path (orbx_fast4.hip: a wave per 64-dword strip and tile
+// row) instead of the 128-pixel tiles of the LDS tile kernel (stage operators)
+int make_bandmap(const OrbxPlan& plan, int nms_radius, OrbxBandMap* bm, std::string* why, bool strips = false) {
   std::memset(bm, 0, sizeof(*bm));
   const int tw = ORBX_FAST3_TW, th = orbx_fast3_tile_h(nms_radius);
   int nb = 0;
   for (int l = 0; l < plan.nlevels; l++) {
-    bm->tiles_x[l] = (plan.L[l].w + tw - 1) / tw;
+    bm->tiles_x[l] = strips ? orbx_fast4_strips(plan.L[l].w, nms_radius) : (plan.L[l].w + tw - 1) / tw;
     bm->tiles_y[l] = (plan.L[l].h + th - 1) / th;
     bm->tile_h[l] = (plan.L[l].h + bm->tiles_y[l] - 1) / bm->tiles_y[l];  // balanced tile rows
     bm->xprefix[l + 1] = bm->xprefix[l] + bm->tiles_x[l];
@@ -479,7 +482,14 @@ int top_rows_env() {
   return v < 0 ? 0 : v;
 }
 
-int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string* why) {
+// ORBX_FAST_IMPL=3: the whole path runs the LDS tile kernel of the stage operators (orbx_fast.hip) instead of the
+// streaming kernel (orbx_fast4.hip).  Same results; read when a context is created (A/B timing in one process).
+int fast_impl_env() {
+  const char* e = getenv("ORBX_FAST_IMPL");
+  return e && atoi(e) == 3 ? 3 : 4;
+}
+
+int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string* why, int fast_impl = 4) {
   std::memset(plan, 0, sizeof(*plan));
   plan->nlevels = p.nlevels;
   plan->w0 = w0;
@@ -497,7 +507,13 @@ int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string
     L.pitch = align_up(L.w, 64);
     L.img_off = (int32_t)img_off;
     img_off = align_up_sz(img_off + (size_t)L.pitch * L.h, 256);
-    L.mask_wpr = (L.w + 63) / 64;
+    // the whole path's FAST kernel writes its survivor masks in strip layout (orbx_fast4.hip)
+    if (fast_impl == 4) {
+      L.mask_strip_px = 4 * orbx_fast4_strip_lanes(p.nms_window / 2);
+      L.mask_wpr = 4 * orbx_fast4_strips(L.w, p.nms_window / 2);
+    } else {
+      L.mask_wpr = (L.w + 63) / 64;
+    }
     L.mask_off = (int32_t)mask_off;
     mask_off += (size_t)L.mask_wpr * L.h;
     int quota;
@@ -661,7 +677,7 @@ int set_plan(orbx_ctx* c, int w, int h) {
     return fail(c, ORBX_ERR_INVALID_ARG, "frame size outside [8, max_width] x [8, max_height]");
   OrbxPlan plan;
   std::string why;
-  int st = build_plan(c->p, w, h, &plan, &why);
+  int st = build_plan(c->p, w, h, &plan, &why, c->fast_impl);
   if (st != ORBX_OK) return fail(c, st, why);
   make_taps(plan, &c->h_taps);
   if (c->h_taps.size() > c->taps_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "resize table exceeds pool");
@@ -682,7 +698,7 @@ int set_plan(orbx_ctx* c, int w, int h) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   make_tilemap(plan, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &c->tm_blur);
-  if ((st = make_bandmap(plan, c->p.nms_window / 2, &c->bm_fast, &why)) != ORBX_OK) return fail(c, st, why);
+  if ((st = make_bandmap(plan, c->p.nms_window / 2, &c->bm_fast, &why, c->fast_impl == 4)) != ORBX_OK) return fail(c, st, why);
   {
     std::vector<OrbxTileDesc> t;
     build_blur_tiles(plan, &t);
@@ -763,6 +779,16 @@ int fast_early_env() {  // ORBX_FAST_EARLY=0: every tile does the full work (res
 }
 bool fast_early_on(const orbx_ctx* c) { return fast_early_env() && c->fast_early; }
 
+// FAST + NMS over tiles [first, first + count) of the context's band-major table
+hipError_t launch_fast_tiles(orbx_ctx* c, hipStream_t s, int first, int count, int n, OrbxFastParams fp,
+                             unsigned long long* stat, int chunk_scale = 1) {
+  if (c->fast_impl == 4)
+    return orbx_launch_fast4(s, c->d_tiles_fast + first, count, n, final_pyr(c), c->plan.frame_bytes, c->plan.mask_words, fp,
+                             c->d_mask, stat);
+  return orbx_launch_fast_nms(s, c->d_tiles_fast + first, count, n, final_pyr(c), c->plan.frame_bytes, c->plan.mask_words,
+                              fp, c->d_mask, nullptr, stat, chunk_scale);
+}
+
 hipError_t launch_fast_whole(orbx_ctx* c, hipStream_t s, int n, OrbxFastParams fp, bool stats_zeroed = false) {
   unsigned long long* stat = fast_early_on(c) ? c->d_row_stat : nullptr;
   if (stat && !stats_zeroed) {
@@ -771,8 +797,7 @@ hipError_t launch_fast_whole(orbx_ctx* c, hipStream_t s, int n, OrbxFastParams f
   }
   // (a two-launch variant -- tile row 0 first, the rest in strips of several tiles per
   // workgroup -- was measured slower: the kernel boundary costs more than the cheaper exits save)
-  return orbx_launch_fast_nms(s, c->d_tiles_fast, c->fast_tiles_count, n, final_pyr(c), c->plan.frame_bytes,
-                              c->plan.mask_words, fp, c->d_mask, nullptr, stat);
+  return launch_fast_tiles(c, s, 0, c->fast_tiles_count, n, fp, stat);
 }
 
 // separable kind -> register-streaming kernel; /273 kind -> LDS tile kernel.
@@ -862,15 +887,13 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
                                     row_stride, frame_stride, c->d_taps, c->d_pyr_blur, pyr_group_env(), nullptr, nullptr, nullptr,
                                     c->d_row_stat));
       HIPCHK(c, mark(ORBX_NUM_STAGE_TIMES + 1, true));
-      HIPCHK(c, orbx_launch_fast_nms(s, c->d_tiles_fast, first_tiles, n, final_pyr(c), P.frame_bytes, P.mask_words, fp,
-                                     c->d_mask, nullptr, c->d_row_stat));
+      HIPCHK(c, launch_fast_tiles(c, s, 0, first_tiles, n, fp, c->d_row_stat));
       HIPCHK(c, mark(ORBX_NUM_STAGE_TIMES + 2, true));
       HIPCHK(c, orbx_launch_pyrblur(s, c->d_tiles_pyrblur_rest, c->pyrblur_rest_count, P.frame_bytes, P.w0, P.h0, n,
                                     d_frames, row_stride, frame_stride, c->d_taps, c->d_pyr_blur, pyr_group_env(),
                                     c->d_row_stat, c->d_feedback, &c->top_levels));
       HIPCHK(c, mark(2, true));
-      HIPCHK(c, orbx_launch_fast_nms(s, c->d_tiles_fast + first_tiles, c->fast_tiles_count - first_tiles, n, final_pyr(c),
-                                     P.frame_bytes, P.mask_words, fp, c->d_mask, nullptr, c->d_row_stat, 4));
+      HIPCHK(c, launch_fast_tiles(c, s, first_tiles, c->fast_tiles_count - first_tiles, n, fp, c->d_row_stat, 4));
     }
   } else {
     HIPCHK(c, launch_pyramid_auto(c, s, n, d_frames, row_stride, frame_stride));
@@ -1180,7 +1203,8 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
   c->p = *p;
   c->device = dev;
 
-  st = build_plan(c->p, p->max_width, p->max_height, &c->plan_max, &why);
+  c->fast_impl = fast_impl_env();
+  st = build_plan(c->p, p->max_width, p->max_height, &c->plan_max, &why, c->fast_impl);
   if (st != ORBX_OK) {
     delete c;
     return fail(nullptr, st, why);
@@ -1214,7 +1238,7 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
   c->h_feedback[0] = c->h_feedback[1] = 0;
   {
     OrbxBandMap bmm;
-    if ((st = make_bandmap(M, p->nms_window / 2, &bmm, &why)) != ORBX_OK) {
+    if ((st = make_bandmap(M, p->nms_window / 2, &bmm, &why, c->fast_impl == 4)) != ORBX_OK) {
       orbx_destroy(c);
       return fail(nullptr, st, why);
     }
@@ -1295,7 +1319,7 @@ int orbx_get_plan(orbx_ctx* c, int width, int height, int32_t* level_w, int32_t*
   if (!c) return ORBX_ERR_INVALID_ARG;
   OrbxPlan plan;
   std::string why;
-  int st = build_plan(c->p, width, height, &plan, &why);
+  int st = build_plan(c->p, width, height, &plan, &why, c->fast_impl);
   if (st != ORBX_OK) return fail(c, st, why);
   for (int l = 0; l < plan.nlevels; l++) {
     if (level_w) level_w[l] = plan.L[l].w;

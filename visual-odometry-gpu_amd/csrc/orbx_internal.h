@@ -28,7 +28,15 @@ struct OrbxLevel {
   float scale;       // (float)pow(scaleFactor, l)  src/orb.cpp:95
   int32_t out_off;   // first STATIC selection slot of this level = sum of the lower levels' quotas
   int32_t win8;      // resize: the 4 source pairs of any aligned group of 4 outputs fit one 8-byte window
+  // 0: classic mask rows (bit x & 63 of word x >> 6).  > 0: STRIP layout of the streaming FAST kernel
+  // (orbx_fast4.hip): 4 words per strip and row, word 4 s + q of a row holds pixels mask_strip_px * s + 64 q + bit
+  // (a strip's first / last halo pixels are zero bits), so x = (xw >> 2) * mask_strip_px + (xw & 3) * 64 + bit
+  int32_t mask_strip_px;
 };
+// pixel x of bit `b` of mask word `xw` of a row
+__host__ __device__ inline int orbx_mask_x(const OrbxLevel& L, int xw, int b) {
+  return L.mask_strip_px ? (xw >> 2) * L.mask_strip_px + (xw & 3) * 64 + b : xw * 64 + b;
+}
 
 struct OrbxPlan {
   int32_t nlevels;
@@ -114,6 +122,14 @@ struct OrbxFastParams {
 constexpr int orbx_fast3_tile_h(int nms_radius) {
   return (256 / (ORBX_FAST3_TW / 4 + 2)) * ORBX_FAST3_K - 2 * nms_radius;
 }
+// streaming FAST kernel (orbx_fast4.hip): a wave owns a strip of 64 dwords; the outer `halo` dwords of a side are
+// context for the ring (3 px) and the NMS window (R px) of the pixels next to them; tile rows as above
+constexpr int orbx_fast4_halo(int nms_radius) { return (nms_radius + 3 + 3) / 4; }
+constexpr int orbx_fast4_strip_lanes(int nms_radius) { return 64 - 2 * orbx_fast4_halo(nms_radius); }
+constexpr int orbx_fast4_strips(int w, int nms_radius) {
+  const int ndw = (w + 3) / 4, s = orbx_fast4_strip_lanes(nms_radius), n = (ndw - 2 * orbx_fast4_halo(nms_radius) + s - 1) / s;
+  return n < 1 ? 1 : n;
+}
 // tile geometry of the blur kernel
 #define ORBX_BLUR_TW 64
 #define ORBX_BLUR_TH 16
@@ -175,6 +191,11 @@ hipError_t orbx_launch_fast_nms(hipStream_t s, const OrbxTileDesc* d_tiles, int 
                                 const uint8_t* d_pyr, int frame_bytes, int mask_words, OrbxFastParams fp,
                                 unsigned long long* d_mask, uint16_t* d_scores,
                                 unsigned long long* d_row_stat, int chunk_scale = 1);
+// streaming FAST + NMS of the whole path: d_tiles = (strip, tile row) units of ONE frame in band-major order, masks in
+// strip layout (OrbxLevel::mask_strip_px > 0)
+hipError_t orbx_launch_fast4(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int n_frames, const uint8_t* d_pyr,
+                             int frame_bytes, int mask_words, OrbxFastParams fp, unsigned long long* d_mask,
+                             unsigned long long* d_row_stat);
 hipError_t orbx_launch_compact(hipStream_t s, const OrbxPlan& plan, int n_frames,
                                const unsigned long long* d_mask, orbx_keypoint* d_cand, int32_t* d_cand_count,
                                int32_t* d_cand_total, int need_total);

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_compact(OrbxPlan plan, const u64* __res
         const int b = __ffsll((long long)v) - 1;
         v &= v - 1;
         orbx_keypoint kp;
-        kp.x = xw * 64 + b;
+        kp.x = orbx_mask_x(L, xw, b);
         kp.y = y;
         out[pos++] = kp;
       }
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(LVL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         while (w && pos < cap) {
           const int b = __ffsll((long long)w) - 1;
           w &= w - 1;
-          s_kp[pos++] = ((uint32_t)y << 16) | (uint32_t)(xw * 64 + b);
+          s_kp[pos++] = ((uint32_t)y << 16) | (uint32_t)orbx_mask_x(L, xw, b);
         }
       }
       base += tot;
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(256) void k_lvl_compact(OrbxPlan plan, const u64* _
         while (w && pos < cap) {
           const int b = __ffsll((long long)w) - 1;
           w &= w - 1;
-          out[pos++] = ((uint32_t)y << 16) | (uint32_t)(xw * 64 + b);
+          out[pos++] = ((uint32_t)y << 16) | (uint32_t)orbx_mask_x(L, xw, b);
         }
       }
       base += tot;
@@ -1133,12 +1133,6 @@ __device__ __forceinline__ void describe_wave(const DescJob& jb, DescLds& lds, i
 // workgroup's threads), 1 for the few-keypoint / single-frame case where the chip is nearly empty and the
 // latency of four descriptor passes in a row is what counts
 
-__device__ __forceinline__ void wave_lds_sync() {
-  // LDS operations of one wave execute in order; this only pins the compiler
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 #define DESC_NLD ((DESC_ROWS * (DESC_PITCH / 4) + 63) / 64)  // dwords per lane per patch (8)
 

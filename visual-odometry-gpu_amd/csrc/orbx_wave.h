@@ -51,3 +51,10 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ss2_t, a), __builtin_bit_cast(ss2_t, b)));
 }
+
+// LDS hand-over between the lanes of ONE wave: its LDS operations execute in order, this only pins the compiler
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
