@@ -18,6 +18,14 @@ import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["3", "4"], ids=["fast-tiles", "fast-stream"])
+def fast_impl(request, monkeypatch):
+    """Every test of this module runs with both FAST kernels of the whole path: the LDS tile kernel (orbx_fast.hip,
+    the default) and the register-streaming one (orbx_fast4.hip); ORBX_FAST_IMPL is read when a context is created."""
+    monkeypatch.setenv("ORBX_FAST_IMPL", request.param)
+    return request.param
+
 PK = dict(nfeatures=1000, nlevels=8, scale_factor=1.2, threshold=20, n=9, nms_window=3, patch_size=31,
           blur_levels=2, blur_kind=0)
 B, W, H = 64, 1241, 376

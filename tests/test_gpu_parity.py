@@ -13,6 +13,14 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["3", "4"], ids=["fast-tiles", "fast-stream"])
+def fast_impl(request, monkeypatch):
+    """Every test of this module runs with both FAST kernels of the whole path: the LDS tile kernel (orbx_fast.hip,
+    the default) and the register-streaming one (orbx_fast4.hip); ORBX_FAST_IMPL is read when a context is created."""
+    monkeypatch.setenv("ORBX_FAST_IMPL", request.param)
+    return request.param
+
+
 def synth(seed, h, w, kind="rects"):
     """Seeded synthetic frame with KITTI-like statistics (stream B, simplified)."""
     rng = np.random.default_rng(seed)
@@ -420,7 +428,7 @@ def test_zero_feature_budget(pkg, select_mode):
         assert c.detect_and_compute(img)["count"] == 0
 
 
-def test_fast_tile_counts(pkg, kitti0, kitti1):
+def test_fast_tile_counts(pkg, kitti0, kitti1, fast_impl):
     """orbx_fast_tile_counts: with the early exit off every tile works; with it on, fewer do, and the
     results are the same (checked bit for bit in test_fast_early_exit_is_invisible)."""
     frames = np.stack([kitti0, kitti1] * 4)
@@ -430,13 +438,18 @@ def test_fast_tile_counts(pkg, kitti0, kitti1):
         c.batch_host(frames)
         w0, t0 = c.fast_tile_counts()
         plan = c.plan(1241, 376)
-        tile_h = 47  # 7 groups of 7 centre rows - 2 x NMS radius (orbx_fast3_tile_h(1))
-        # units of the streaming kernel: strips of 64 dwords, the outer dword of a side is halo (62 productive; the
-        # image's own borders need none) x tile rows of <= 47 rows
-        strips = [max(1, -(-(-(-int(w) // 4) - 2) // 62)) for w in plan["level_w"]]
-        per_frame = sum(s * -(-int(h) // tile_h) for s, h in zip(strips, plan["level_h"]))
-        assert w0 == t0 and t0 == 8 * per_frame == 8 * 146
-        row0 = sum(strips)  # tile row 0 of every level: 26 units per frame
+        tile_h = 47  # orbx_fast3_tile_h(1): 7 x 7 rows of the score region - 2 x NMS radius
+        if fast_impl == "3":  # tiles of 128 x <= 47
+            cols = [-(-int(w) // 128) for w in plan["level_w"]]
+            want = 272
+        else:
+            # units of the streaming kernel: strips of 64 dwords, the outer dword of a side is halo (62 productive;
+            # the image's own borders need none) x tile rows of <= 47 rows
+            cols = [max(1, -(-(-(-int(w) // 4) - 2) // 62)) for w in plan["level_w"]]
+            want = 146
+        per_frame = sum(s * -(-int(h) // tile_h) for s, h in zip(cols, plan["level_h"]))
+        assert w0 == t0 and t0 == 8 * per_frame == 8 * want
+        row0 = sum(cols)  # tile row 0 of every level
         c.set_fast_early_exit(True)
         c.batch_host(frames)
         w1, t1 = c.fast_tile_counts()

@@ -175,7 +175,7 @@ struct orbx_ctx {
 
   int timing = 0;  // 0 off, 1 all stages, 2 blur + fast only
   int fast_early = 1;
-  int fast_impl = 4;  // 4: streaming FAST kernel (orbx_fast4.hip), 3: LDS tile kernel (ORBX_FAST_IMPL, read at creation)
+  int fast_impl = 3;  // 3: LDS tile kernel (orbx_fast.hip), 4: streaming kernel (orbx_fast4.hip); ORBX_FAST_IMPL, read at creation
   int fuse = 1;  // pyramid + blur in one kernel when blur runs on every level (orbx_set_fused_pyramid_blur)
   // Top-rows-first pipeline (enqueue_batch): 0 never, 1 whenever eligible, 2 adaptive -- the second pass
   // counts the (frame, level)s it skipped / had to produce (d_feedback, running totals, written to the pinned
@@ -482,14 +482,15 @@ int top_rows_env() {
   return v < 0 ? 0 : v;
 }
 
-// ORBX_FAST_IMPL=3: the whole path runs the LDS tile kernel of the stage operators (orbx_fast.hip) instead of the
-// streaming kernel (orbx_fast4.hip).  Same results; read when a context is created (A/B timing in one process).
+// ORBX_FAST_IMPL=4: the whole path runs the register-streaming kernel (orbx_fast4.hip) instead of the LDS tile kernel
+// (orbx_fast.hip).  Same results, same speed within ~2 % on the benchmark stream (profiles/r03: 12 % fewer vector
+// instructions, but 14 instead of 24 waves per CU); read when a context is created (A/B timing in one process).
 int fast_impl_env() {
   const char* e = getenv("ORBX_FAST_IMPL");
-  return e && atoi(e) == 3 ? 3 : 4;
+  return e && atoi(e) == 4 ? 4 : 3;
 }
 
-int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string* why, int fast_impl = 4) {
+int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string* why, int fast_impl = 3) {
   std::memset(plan, 0, sizeof(*plan));
   plan->nlevels = p.nlevels;
   plan->w0 = w0;

@@ -114,7 +114,7 @@ __device__ __forceinline__ void f3_decode(uint32_t e, int keff, int& sr, int& sc
 // live across it -- paid for that with ~150 v_writelane / v_readlane spill instructions per tile.
 template <int R, int NARC>
 __device__ __forceinline__ void f3_eval(const uint8_t* s_img, uint16_t* s_score, uint16_t* s_queue, int nq, int thr,
-                                        int n, int keff, int tid) {
+                                        int n, int keff, int tid, const uint8_t* s_lut) {
   typedef F3<R> G;
   typedef F3Ring<G::IMG_PITCH> RG;
   const int narc = NARC > 0 ? NARC : n;
@@ -131,14 +131,26 @@ __device__ __forceinline__ void f3_eval(const uint8_t* s_img, uint16_t* s_score,
     int v[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) v[k] = p0[RG::off(k)];
-    const int hi = Ip + thr, lo = Ip - thr;
-    uint32_t nb = 0, nd = 0;
+    // The 16 comparisons per polarity come out of a table (ring pixel - centre + 255 -> bit 0: brighter by >= t,
+    // bit 1: darker by >= t; src/orb_cpu.cpp:75-83): ONE add per ring pixel (its address) and one shift-or that
+    // moves the pixel's two bits into a 32-bit word -- 16 pixels x 2 bits = the whole circle, so "n contiguous" is
+    // rotate-and-AND on that word for both polarities at once (rotations by even amounts keep them apart).
+    // 44 vector instructions where sub + v_alignbit per pixel and polarity and two run tests took 84.
+    const uint8_t* lut = s_lut + (255 - Ip);
+    uint32_t M = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      nb = __builtin_amdgcn_alignbit(nb, (uint32_t)(v[k] - hi), 31);  // bit = v < hi
-      nd = __builtin_amdgcn_alignbit(nd, (uint32_t)(lo - v[k]), 31);  // bit = v > lo
-    }
-    const bool corner = f3_has_run16(~nb & 0xffffu, narc) || f3_has_run16(~nd & 0xffffu, narc);
+    for (int k = 0; k < 16; k++) M = (M << 2) | (uint32_t)lut[v[k]];
+    auto rot = [](uint32_t x, int sh) { return __builtin_amdgcn_alignbit(x, x, sh); };
+    uint32_t a = M;
+    int kk = 1;
+#pragma unroll
+    for (int st = 0; st < 4; st++)
+      if (2 * kk <= narc) {
+        a &= rot(a, 2 * kk);
+        kk *= 2;
+      }
+    if (kk < narc) a &= rot(a, 2 * (narc - kk));
+    const bool corner = a != 0u;
     uint32_t score = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) score = __builtin_amdgcn_sad_u16((uint32_t)Ip, (uint32_t)v[k], score);
@@ -198,6 +210,7 @@ __global__ __launch_bounds__(256, 6) void k_fast3(const OrbxTileDesc* __restrict
   // the store, so the mask is clean again long before the next tile's NMS sets bits
   __shared__ __attribute__((aligned(16))) uint32_t s_mask32[G::TH * G::MASK_DW];
   __shared__ int s_qn;
+  __shared__ __attribute__((aligned(16))) uint32_t s_lut32[128];  // f3_eval's comparison table
   __shared__ int s_wtot[4];
   __shared__ int s_skip_next;
   __shared__ int s_srch[2][4];
@@ -207,6 +220,16 @@ __global__ __launch_bounds__(256, 6) void k_fast3(const OrbxTileDesc* __restrict
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int thr = fp.threshold, n = fp.n;
+  if (tid < 128) {  // (read after the first barrier of the tile loop at the earliest)
+    uint32_t wv = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int dd = 4 * tid + b - 255;
+      wv |= (uint32_t)((dd >= thr ? 1 : 0) | (dd <= -thr ? 2 : 0)) << (8 * b);
+    }
+    s_lut32[tid] = wv;
+  }
+  const uint8_t* s_lut = reinterpret_cast<const uint8_t*>(s_lut32);
   // this workgroup's tiles: `chunk` consecutive linear indices (the same tile of consecutive frames)
   const int lin0 = (int)blockIdx.x * chunk, lin_end = min(lin0 + chunk, n_tiles * n_frames);
   auto advance = [&](int& t, int& f) {
@@ -369,11 +392,11 @@ __global__ __launch_bounds__(256, 6) void k_fast3(const OrbxTileDesc* __restrict
     const int ntot = s_qn;
     auto eval = [&](int nq) {
       if (n == 9)
-        f3_eval<R, 9>(s_img, score0, s_queue, nq, thr, n, keff, tid);
+        f3_eval<R, 9>(s_img, score0, s_queue, nq, thr, n, keff, tid, s_lut);
       else if (n == 12)
-        f3_eval<R, 12>(s_img, score0, s_queue, nq, thr, n, keff, tid);
+        f3_eval<R, 12>(s_img, score0, s_queue, nq, thr, n, keff, tid, s_lut);
       else
-        f3_eval<R, 0>(s_img, score0, s_queue, nq, thr, n, keff, tid);
+        f3_eval<R, 0>(s_img, score0, s_queue, nq, thr, n, keff, tid, s_lut);
     };
     if (ntot <= G::QCAP) {  // block-uniform
       // ---- phase 3: full segment test + score of the candidates

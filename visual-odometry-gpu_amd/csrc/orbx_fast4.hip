@@ -31,7 +31,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <cstdlib>
 
 #include "orbx_fast_common.h"
 #include "orbx_internal.h"
@@ -98,8 +97,7 @@ __global__ __launch_bounds__(64) void k_fast4(const OrbxTileDesc* __restrict__ t
   }
   const int w = d.w, h = d.h, pitch = d.pitch, th = d.f;
   const int y0 = d.ty * th, y1 = min(y0 + th, h);
-  const int thr = fp.threshold, narc_any = fp.n & 0xff;
-  const int abl = fp.n >> 8;  // ORBX_F4_ABL: timing experiments only (results are wrong)
+  const int thr = fp.threshold, narc_any = fp.n;
   const bool first = d.tx == 0, last = d.tx + 1 == d.u2;
   const int dw0 = d.tx * C::S;
   const int x_lane = 4 * (dw0 + lane);
@@ -194,7 +192,6 @@ __global__ __launch_bounds__(64) void k_fast4(const OrbxTileDesc* __restrict__ t
     }
     // row k of the group sits in bit k + 1 of every byte
     uint32_t cand = (~acc >> 1) & scol & f4_rowmask(cy0, sy_lo, sy_hi);
-    if (abl & 8) cand = 0u;
     if (R == 0) cand &= pcol & f4_rowmask(cy0, y0, y1);
 
     // ---- a pass over the set bits of `bits`, 64 at a time: fn(active, entry), entry = lane << 5 | byte << 3 | row.
@@ -296,7 +293,7 @@ __global__ __launch_bounds__(64) void k_fast4(const OrbxTileDesc* __restrict__ t
         }
       }
     };
-    if (!(abl & 1)) for_each(cand, eval);
+    for_each(cand, eval);
 
     if (R > 0) {
       // corners back to their lanes; NMS row n of this group = centre row 7 g - R + n: the last R rows of the
@@ -332,7 +329,7 @@ __global__ __launch_bounds__(64) void k_fast4(const OrbxTileDesc* __restrict__ t
         }
         if (active && keep) atomicOr(&s_mask32[n * 8 + (xs >> 5)], 1u << (xs & 31));
       };
-      if (!(abl & 2)) for_each(nbits, nms);
+      for_each(nbits, nms);
     }
 
     // ---- the mask rows this group finished: lane = (row, word); every row of the tile row leaves exactly once
@@ -384,11 +381,6 @@ hipError_t orbx_launch_fast4(hipStream_t s, const OrbxTileDesc* d_tiles, int n_t
   if (n_tiles <= 0 || n_frames <= 0) return hipSuccess;
   const long long total = (long long)n_tiles * n_frames;
   if (total > 0x7fffffffll) return hipErrorInvalidValue;
-  static const int abl = [] {
-    const char* e = getenv("ORBX_F4_ABL");
-    return e ? atoi(e) : 0;
-  }();
-  fp.n |= abl << 8;
   switch (fp.nms_radius) {
     case 0:
       launch_fast4<0>((unsigned)total, s, d_tiles, n_tiles, n_frames, d_pyr, frame_bytes, mask_words, fp, d_mask, d_row_stat);
