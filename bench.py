@@ -45,55 +45,7 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 T
 HBM_COPY_GBS = 6290.0      # same guide: measured float4 copy
 VALU_CLOCK_GHZ = 2.4       # same guide: max clock; one wave64 VALU instruction holds its SIMD for 4 clocks
 N_SIMD = 1024              # 256 CUs x 4
-PMC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_counters.json")
-
-
-def stream_a(n, first=0):
-    """SURVEY.md §8(d) stream A: frames derived deterministically from the two
-    reference KITTI fixtures (roll + small Gaussian noise), KITTI statistics kept."""
-    import oracle_lib as O  # only for load_kitti (reads tests/golden/*.npz)
-
-    base = [O.load_kitti(0), O.load_kitti(1)]
-    out = np.empty((n,) + base[0].shape, np.uint8)
-    for j in range(n):
-        i = first + j
-        rng = np.random.default_rng(1000 + i)
-        img = np.roll(base[i & 1], ((3 * i) % 17, (5 * i) % 11), (0, 1)).astype(np.int16)
-        img += np.rint(rng.normal(0.0, 2.0, img.shape)).astype(np.int16)
-        out[j] = np.clip(img, 0, 255).astype(np.uint8)
-    return out
-
-
-def stream_a_device(torch, first, n, device):
-    """The same recipe generated on the GPU (a per-frame seeded torch generator instead of numpy's):
-    8000 frames take ~1 s instead of ~80 s of host time.  Frame i depends on i only, so any sharding
-    of the stream sees the same frames."""
-    import oracle_lib as O
-
-    base = [torch.from_numpy(O.load_kitti(k)).to(device).to(torch.int16) for k in (0, 1)]
-    out = torch.empty((n,) + tuple(base[0].shape), dtype=torch.uint8, device=device)
-    g = torch.Generator(device=device)
-    for j in range(n):
-        i = first + j
-        g.manual_seed(1000 + i)
-        noise = torch.round(torch.randn(base[0].shape, generator=g, device=device) * 2.0).to(torch.int16)
-        img = torch.roll(base[i & 1], shifts=((3 * i) % 17, (5 * i) % 11), dims=(0, 1)) + noise
-        out[j] = img.clamp_(0, 255).to(torch.uint8)
-    return out
-
-
-def stream_b(n, h, w, first=0):
-    """SURVEY.md §8(d) stream B: synthetic frames of any resolution."""
-    out = np.empty((n, h, w), np.uint8)
-    for j in range(n):
-        rng = np.random.default_rng(first + j)
-        img = 89.0 + 30.0 * rng.standard_normal((h, w))
-        for _ in range(400):
-            x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
-            ww, hh = int(rng.integers(4, 120)), int(rng.integers(4, 120))
-            img[y0:y0 + hh, x0:x0 + ww] += rng.uniform(20, 120) * rng.choice([-1, 1])
-        out[j] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
-    return out
+PMC_FILE = os.path.join(ROOT, "profiles", "r03", "pmc_counters.json")
 
 
 def host_threads():
@@ -116,6 +68,32 @@ def oracle_results(frames, params_kw):
         return list(ex.map(lambda f: O.detect_and_compute_gpu(f, op), frames))
 
 
+def compare_with_oracle(pkg, frames, params_kw, counts, kps, desc):
+    """keypoint lists and descriptor checksum of `frames` through the oracle against (counts, kps, desc)."""
+    ref = oracle_results(frames, params_kw)
+    want_cs = pkg.shard.descriptor_checksum([len(r["kps"]) for r in ref], [r["desc"] for r in ref])
+    got_cs = pkg.shard.descriptor_checksum(counts, desc)
+    kp_ok = all(int(counts[i]) == len(r["kps"]) and np.array_equal(kps[i, :len(r["kps"])], r["kps"]) for i, r in enumerate(ref))
+    return {"checksum_match": bool(want_cs == got_cs), "keypoints_match": bool(kp_ok), "frames_checked": len(ref),
+            "oracle_keypoints": int(sum(len(r["kps"]) for r in ref))}
+
+
+def read_sclk_mhz():
+    """Current shader clock from sysfs (the line of pp_dpm_sclk marked with *), or None."""
+    import glob
+
+    best = None
+    for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
+        try:
+            for line in open(f):
+                if "*" in line:
+                    mhz = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+                    best = mhz if best is None else max(best, mhz)
+        except (OSError, ValueError, IndexError):
+            pass
+    return best
+
+
 def cpu_baseline(frames, params_kw, budget_s=10.0, max_frames=4096):
     """The CPU oracle (a port of orb_cpu.cpp + the orb.cpp orchestrator intent)
     timed single-threaded on a bounded sample of the same workload."""
@@ -132,8 +110,8 @@ def cpu_baseline(frames, params_kw, budget_s=10.0, max_frames=4096):
             break
     dt = time.perf_counter() - t0
     out = {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": "%d stream-A frames 1241x376 (the step's batch, cycled), same parameters, "
-                     "oracle/liborb_oracle.so single thread, %.1f s" % (done, dt)}
+           "sample": "%d frames %dx%d (the step's batch, cycled), same parameters, "
+                     "oracle/liborb_oracle.so single thread, %.1f s" % (done, frames.shape[2], frames.shape[1], dt)}
     # the same oracle frame-parallel over the host cores this process may use (the
     # reference itself is single-threaded, so this is the most a frame-parallel CPU run of it could give)
     import threading
@@ -160,7 +138,9 @@ def cpu_baseline(frames, params_kw, budget_s=10.0, max_frames=4096):
                         "sample": "%d frames over %d threads, %.1f s" % (sum(counts), nthr, dt2)}
     # BASELINE.json configs[0] / BASELINE.md §3: orb_cpu.cpp detectAndCompute on 000000.png, CPU-flavour
     # defaults (threshold 50, patch 9, cap 3000, ONE level), single thread
-    k0 = O.load_kitti(0)
+    import importlib
+
+    k0 = importlib.import_module("visual-odometry-gpu_amd").streams.load_kitti(0)
     O.detect_and_compute_cpu(k0)
     t2, n0 = time.perf_counter(), 0
     while time.perf_counter() - t2 < 2.0:
@@ -204,7 +184,11 @@ def main():
     ap.add_argument("--rotate", type=int, default=2, help="distinct resident input batches the steps rotate over")
     ap.add_argument("--workload", default="kitti", choices=["kitti", "1080p"])
     ap.add_argument("--stream-frames", type=int, default=0,
-                    help="config 3: a stream of 8*F frames split over the ranks, each rank walks its block once")
+                    help="config 3 as the TIMED region: a stream of 8*F frames split over the ranks, each rank walks its block once")
+    ap.add_argument("--strong-frames", type=int, default=None,
+                    help="config 3 beside the weak-scaling line (`stream` block): 8*F frames split over the ranks; "
+                         "default 1000 (0 with --only-timed); 0: skip")
+    ap.add_argument("--sustain-s", type=float, default=1.0, help="length of the sustained run (`value_sustained`); 0: skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl == RCCL; gloo only to rehearse N>1 on a one-GPU box)")
@@ -266,7 +250,7 @@ def main():
     if stream_mode:
         total = 8 * args.stream_frames
         first, last = pkg.shard.split_stream(total, rank, world)
-        d_all = stream_a_device(torch, first, last - first, dev)
+        d_all = pkg.streams.stream_a_device(torch, first, last - first, dev)
         nlocal = last - first
         nbatches = (nlocal + B - 1) // B
         batches = [(d_all[i * B:min((i + 1) * B, nlocal)], min(B, nlocal - i * B)) for i in range(nbatches)]
@@ -278,9 +262,9 @@ def main():
         steps = args.steps if args.steps is not None else 20
         f0 = pkg.shard.frame_range(rank, world, R * B)[0]
         if args.workload == "kitti":
-            host = [stream_a(B, first=f0 + r * B) for r in range(R)]
+            host = [pkg.streams.stream_a(B, first=f0 + r * B) for r in range(R)]
         else:
-            host = [stream_b(B, H, W, first=f0 + r * B) for r in range(R)]
+            host = [pkg.streams.stream_b(B, H, W, first=f0 + r * B) for r in range(R)]
         batches = [(torch.from_numpy(h).to(dev), B) for h in host]
         frames0 = host[0]
     torch.cuda.synchronize()
@@ -337,6 +321,78 @@ def main():
     fast_tiles = ctx.fast_tile_counts()  # (did the full work, all) of the last timed step
     pyr_done = ctx.pyramid_pixel_counts()  # (pyramid pixels produced, all) of the last timed step
     roof_ms = {"blur": 0.0, "fast_nms": 0.0}
+    # ---- what the timed region itself produced: the result blocks of its LAST TWO steps (one per lane when
+    # pipelined), copied out before anything else runs; compared with the oracle at the end (`parity.timed_region`)
+    timed_out = []
+    if not stream_mode and steps >= 2:
+        for prev in (False, True):
+            hv = ctx.batch_host_view(previous=prev)
+            timed_out.append({"batch": (steps - 1 - (1 if prev else 0)) % len(batches), "counts": hv["counts"].copy(),
+                              "kps": hv["kps"].copy(), "desc": hv["desc"].copy()})
+
+    # ---- the same timed region with every FAST tile working and every pyramid row produced (`value_full_work`:
+    # what a stream that never fills its caps in the top rows gets), and a sustained run (`value_sustained`)
+    def timed_run(nsteps, nb=None):
+        nb = len(batches) if nb is None else nb
+        barrier()
+        t_ = time.perf_counter()
+        nfr = 0
+        for i in range(nsteps):
+            t, n = batches[i % nb]
+            ctx.batch_device(t.data_ptr(), n, W, H)
+            nfr += n
+        ctx.wait()
+        barrier()
+        return grp.sum_int(nfr) / grp.max_float(time.perf_counter() - t_)
+
+    value_full_work = value_sustained = sustained_info = None
+    if not args.only_timed and not stream_mode and not args.full_work:
+        ctx.set_fast_early_exit(False)
+        for i in range(2):
+            submit(i)
+        ctx.wait()
+        value_full_work = timed_run(steps)
+        ctx.set_fast_early_exit(True)
+        for i in range(2):
+            submit(i)
+        ctx.wait()
+    if not args.only_timed and not stream_mode and args.sustain_s > 0:
+        # >= 8 distinct resident batches (the graph cache holds 8 batch shapes: (input, result block) pairs)
+        nb8 = 8
+        base_first = pkg.shard.frame_range(rank, world, len(batches) * B)[0] + world * len(batches) * B
+        while len(batches) < nb8:
+            k = len(batches)
+            gen = pkg.streams.stream_a if args.workload == "kitti" else (lambda n, first: pkg.streams.stream_b(n, H, W, first))
+            batches.append((torch.from_numpy(gen(B, first=base_first + k * B)).to(dev), B))
+        for i in range(nb8):
+            submit(i)
+        ctx.wait()
+        rate = timed_run(2 * nb8)  # calibration
+        nst = max(2 * nb8, int(args.sustain_s * rate / (world * B)) // nb8 * nb8)
+        clocks = []
+        import threading
+
+        stop = threading.Event()
+
+        def sample():
+            while not stop.is_set():
+                c_ = read_sclk_mhz()
+                if c_:
+                    clocks.append(c_)
+                stop.wait(0.1)
+
+        th = threading.Thread(target=sample)
+        th.start()
+        value_sustained = timed_run(nst)
+        stop.set()
+        th.join()
+        sustained_info = {"steps": nst, "distinct_resident_batches": nb8, "seconds": nst * B * world / value_sustained,
+                          "sclk_mhz_sysfs_median": (sorted(clocks)[len(clocks) // 2] if clocks else None),
+                          "sclk_samples": len(clocks)}
+        del batches[max(1, args.rotate):]
+        for i in range(2):
+            submit(i)
+        ctx.wait()
     if pipelined:
         ctx.set_pipelined_batches(False)  # the per-stage passes below run one batch at a time
     else:
@@ -362,6 +418,46 @@ def main():
                        "frames_per_s_strong": None}
         if steps == len(batches):  # the timed region was exactly one pass over every rank's block
             stream_info["frames_per_s_strong"] = stream_info["total_frames"] / dt
+
+    # ---- BASELINE.json configs[3] beside the weak-scaling line: a stream of 8 x F distinct frames split over the
+    # ranks in contiguous blocks, every rank keeps its block resident and walks it ONCE (strong scaling: the total
+    # is fixed); the all-reduced keypoint count and descriptor checksum are the same for every world size
+    # (N = 1 reference values: profiles/r03/README.md)
+    def strong_scaling_block(F):
+        total = 8 * F
+        first, last = pkg.shard.split_stream(total, rank, world)
+        d_all = pkg.streams.stream_a_device(torch, first, last - first, dev)
+        nlocal = last - first
+        sb = [(d_all[i * B:min((i + 1) * B, nlocal)], min(B, nlocal - i * B)) for i in range((nlocal + B - 1) // B)]
+        torch.cuda.synchronize()
+        ctx.enable_stage_timing(0)
+        ctx.set_pipelined_batches(True)
+        for t, n in sb[:2]:
+            ctx.batch_device(t.data_ptr(), n, W, H)
+        ctx.wait()
+        barrier()
+        t_ = time.perf_counter()
+        for t, n in sb:
+            ctx.batch_device(t.data_ptr(), n, W, H)
+        ctx.wait()
+        barrier()
+        dt_ = grp.max_float(time.perf_counter() - t_)
+        ctx.set_pipelined_batches(False)
+        kp_local, cs_local = 0, 0
+        for t, n in sb:
+            ctx.batch_device(t.data_ptr(), n, W, H)
+            res = ctx.batch_fetch(0, n, cap)
+            kp_local += int(res["counts"].sum())
+            cs_local = (cs_local + pkg.shard.descriptor_checksum(res["counts"], res["desc"])) & 0x7FFFFFFFFFFFFFFF
+        del d_all, sb
+        return {"total_frames": total, "frames_this_rank": nlocal, "frames_per_s_strong": total / dt_, "seconds": dt_,
+                "keypoints": grp.sum_int(kp_local), "desc_checksum": grp.sum_checksum(cs_local),
+                "what": "BASELINE.json configs[3]: 8 x %d stream-A frames (device generator), contiguous block per rank, "
+                        "walked once, pipelined batches of %d; strong scaling" % (F, B)}
+
+    strong_frames = args.strong_frames if args.strong_frames is not None else (0 if args.only_timed else 1000)
+    if not stream_mode and strong_frames > 0 and args.workload == "kitti":
+        stream_info = strong_scaling_block(strong_frames)
 
     # ---- untimed passes: all-stage breakdown with the timed configuration, then with every FAST tile working
     nb = max(1, min(steps, 10))
@@ -411,9 +507,13 @@ def main():
     # the context's copy stream while batch i+1 runs (orbx_batch_prefetch / orbx_batch_fetch_previous)
     fps_d2h = fps_d2h_blocking = None
     if not args.only_timed:
-        nd = max(steps, 10)  # (one lane: at ~400 k frames/s the 59 KB of results per frame saturate the host link either way)
+        # production shape (pipelined lanes) + orbx_batch_prefetch_compact: counts, keypoints, orientations and
+        # descriptors of every batch land in the pinned mirror while the next batch runs and are read there in place
+        nd = max(steps, 10)
+        if pipelined:
+            ctx.set_pipelined_batches(True)
         submit(0)
-        ctx.batch_prefetch()
+        ctx.batch_prefetch(compact=True)
         t1 = time.perf_counter()
         done = kp_seen = 0
         for i in range(1, nd + 1):
@@ -421,9 +521,11 @@ def main():
             hv = ctx.batch_host_view(previous=True)  # batch i-1, zero-copy from the pinned mirror
             done += len(hv["counts"])
             kp_seen += int(hv["counts"].sum())
-            ctx.batch_prefetch()
+            ctx.batch_prefetch(compact=True)
         ctx.wait()
         fps_d2h = world * done / (time.perf_counter() - t1)
+        if pipelined:
+            ctx.set_pipelined_batches(False)
         t1 = time.perf_counter()
         done = 0
         for i in range(5):
@@ -593,6 +695,7 @@ def main():
             "stage_ms_per_step": stage_ms,
             "stage_ms_per_step_fast_full_work": full_ms,
             "stage_ms_per_step_unfused": unfused_ms,
+            "value_full_work": value_full_work, "value_sustained": value_sustained, "sustained": sustained_info,
             "fps_with_d2h": fps_d2h, "fps_with_d2h_blocking_fetch": fps_d2h_blocking,
             "fps_two_contexts_alternating": two_ctx_fps,
             "single_frame_host_to_host": single,
@@ -603,20 +706,31 @@ def main():
         }
         if stream_info:
             out["stream"] = stream_info
-        if not args.no_cpu_baseline and args.workload == "kitti":
+        if not args.no_cpu_baseline:
             # the oracle on the very frames of batch 0: the bench checks itself (src/compare.cpp:39-62 is the
-            # reference's own, commented-out, CPU-vs-GPU descriptor check)
-            ref = oracle_results(frames0[:n0], pk)
-            want_cs = pkg.shard.descriptor_checksum([len(r["kps"]) for r in ref], [r["desc"] for r in ref])
-            kp_ok = all(int(res0["counts"][i]) == len(r["kps"]) and np.array_equal(res0["kps"][i, :len(r["kps"])], r["kps"])
-                        for i, r in enumerate(ref))
-            out["parity"] = {"checksum_match": bool(want_cs == cs0), "keypoints_match": bool(kp_ok),
-                             "frames_checked": len(ref), "oracle_keypoints": int(sum(len(r["kps"]) for r in ref)),
-                             "what": "every frame of batch 0 through oracle/liborb_oracle.so: keypoint lists equal, "
-                                     "descriptor checksum equal" + (" (rank 0's batch)" if world > 1 else "")}
-            out["cpu_baseline"] = cpu_baseline(frames0, pk)
-        elif not args.no_cpu_baseline:
-            out["cpu_baseline"] = None
+            # reference's own, commented-out, CPU-vs-GPU descriptor check).  1920x1080: the first 8 frames.
+            ncheck = n0 if args.workload == "kitti" else min(n0, 8)
+            par = compare_with_oracle(pkg, frames0[:ncheck], pk, res0["counts"][:ncheck], res0["kps"][:ncheck], res0["desc"][:ncheck])
+            par["what"] = ("frames of batch 0 through oracle/liborb_oracle.so: keypoint lists equal, descriptor checksum "
+                           "equal" + (" (rank 0's batch)" if world > 1 else ""))
+            # ... and on what the TIMED REGION itself left in its result blocks (pipelined lanes, graph replay): the
+            # last two timed steps, one per lane
+            if timed_out:
+                tr = []
+                for to in timed_out:
+                    fr = host[to["batch"]]
+                    nchk = len(fr) if args.workload == "kitti" else min(len(fr), 8)
+                    r_ = compare_with_oracle(pkg, fr[:nchk], pk, to["counts"][:nchk], to["kps"][:nchk], to["desc"][:nchk])
+                    r_["resident_batch"] = to["batch"]
+                    tr.append(r_)
+                par["timed_region"] = {"steps_checked": len(tr), "pipelined": pipelined,
+                                       "checksum_match": all(r_["checksum_match"] for r_ in tr),
+                                       "keypoints_match": all(r_["keypoints_match"] for r_ in tr),
+                                       "frames_checked": sum(r_["frames_checked"] for r_ in tr), "per_step": tr,
+                                       "what": "result blocks of the last two timed steps (one per lane), fetched before "
+                                               "any other pass, against the oracle on their input batches"}
+            out["parity"] = par
+            out["cpu_baseline"] = cpu_baseline(frames0, pk) if args.workload == "kitti" else cpu_baseline(frames0[:8], pk, budget_s=6.0)
         print(json.dumps(out))
     ctx.close()
     if world > 1:

@@ -162,6 +162,12 @@ int orbx_batch_fetch(orbx_ctx* ctx, int first, int n, int32_t* counts, orbx_keyp
  * mirror on the context's copy stream; orbx_batch_fetch / _previous then wait for that copy
  * instead of copying.  The results of batch i must be fetched before batch i+2 is submitted. */
 int orbx_batch_prefetch(orbx_ctx* ctx);
+/* The same for consumers that want what the reference's detectAndCompute returns and nothing else (keypoints,
+ * orientations, descriptors: include/orb.hpp:37): only the counts | keypoints | orientations | descriptors sections
+ * of the block are copied -- 44 instead of 60 bytes per keypoint slot, which is what keeps the copy under the host
+ * link's rate at the benchmark's frame rate.  orbx_batch_results_host then reports responses / levels / level_kps
+ * as NULL; a fetch that asks for them copies the remaining sections first (blocking). */
+int orbx_batch_prefetch_compact(orbx_ctx* ctx);
 /* Zero-copy host view of a result block: pointers into the context's PINNED mirror of the last batch
  * (previous = 0) or of the batch before it (previous = 1), same layout as the device view (fixed
  * stride `slot_capacity` entries per frame; only the first counts[f] entries of frame f are valid).
@@ -217,8 +223,12 @@ int orbx_set_top_rows_first(orbx_ctx* ctx, int mode);
  * empty launches of the other (KITTI, 256 frames per batch: ~8 % more frames/s).  Results are unchanged.  What a
  * caller may do between two such calls without losing the overlap: orbx_batch_prefetch, orbx_batch_results_host /
  * orbx_batch_fetch_previous (they follow the result block's own events); orbx_wait and orbx_batch_fetch wait for the
- * batches concerned; every other entry point waits for both lanes first.  Costs a second set of pools (the first
- * call allocates it).  Batches on a caller's stream, host-frame batches and single frames are not pipelined. */
+ * batches concerned; set_plan (a new frame size), the stage operators that use the pools, orbx_batch_match_consecutive
+ * and orbx_destroy wait for both lanes first.  Costs a second set of pools (the first call allocates it; if that
+ * fails -- ORBX_ERR_HIP -- what had been allocated is freed and the mode stays off).  Batches on a caller's stream,
+ * host-frame batches and single frames are not pipelined, and may be mixed freely with pipelined ones: a batch that
+ * comes to a lane's pools or to a result block on another stream than their previous user makes its stream wait
+ * for that user's event (device-side, no host stall). */
 int orbx_set_pipelined_batches(orbx_ctx* ctx, int enable);
 
 /* Same for the pyramid: pyramid pixels the last whole-path batch PRODUCED out of all pyramid pixels of its

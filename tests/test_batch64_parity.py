@@ -32,9 +32,8 @@ B, W, H = 64, 1241, 376
 
 
 @pytest.fixture(scope="module")
-def frames():
-    bench = importlib.import_module("bench")
-    return bench.stream_a(B)
+def frames(pkg):
+    return pkg.streams.stream_a(B)
 
 
 @pytest.fixture(scope="module")
@@ -104,11 +103,10 @@ _SWITCH_PROBE = r"""
 import importlib, sys
 import torch
 sys.path.insert(0, %r)
-bench = importlib.import_module("bench")
 pkg = importlib.import_module("visual-odometry-gpu_amd")
 PK = %r
 B, W, H = 64, 1241, 376
-frames = bench.stream_a(B)
+frames = pkg.streams.stream_a(B)
 p = pkg.default_params("gpu", max_width=W, max_height=H, max_batch=B, **PK)
 with pkg.Context(p) as c:
     cap = c.plan(W, H)["out_capacity"]

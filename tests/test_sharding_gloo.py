@@ -124,3 +124,36 @@ def test_two_gloo_ranks_with_the_gpu_worker_equal_one_rank(pkg):
     assert two["n_gpus"] == 2 and two["stream"]["frames_this_rank"] == 48
     assert one["stream"]["keypoints"] == two["stream"]["keypoints"] > 50000
     assert one["stream"]["desc_checksum"] == two["stream"]["desc_checksum"]
+
+
+def _run_bench_default(world, port, strong):
+    """bench.py's DEFAULT mode (what the driver launches: weak-scaling timed region) with the configs[3] `stream` block
+    beside it, `world` gloo ranks on GPU 0."""
+    import json
+
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--batch", "16", "--steps", "4",
+            "--warmup", "1", "--no-cpu-baseline", "--only-timed", "--strong-frames", str(strong),
+            "--dist-backend", "gloo", "--all-ranks-on-device0"]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(base, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    return json.loads(outs[0][0].strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+def test_default_bench_line_carries_the_strong_scaling_block(pkg):
+    """The line a driver `--gpus N` run gets is the weak-scaling one (`scaling: weak`); beside it the `stream` block
+    reports BASELINE.json configs[3] (strong scaling: a fixed stream split over the ranks) with a keypoint count and a
+    checksum that do not depend on the world size."""
+    one = _run_bench_default(1, 29651, 12)
+    two = _run_bench_default(2, 29652, 12)
+    assert one["scaling"] == two["scaling"] == "weak" and two["n_gpus"] == 2
+    assert one["stream"]["total_frames"] == two["stream"]["total_frames"] == 96
+    assert two["stream"]["frames_this_rank"] == 48 and two["stream"]["frames_per_s_strong"] > 0
+    assert one["stream"]["keypoints"] == two["stream"]["keypoints"] > 50000
+    assert one["stream"]["desc_checksum"] == two["stream"]["desc_checksum"]

@@ -5,5 +5,5 @@ The directory name contains a hyphen, so import it with
     importlib.import_module("visual-odometry-gpu_amd")
 (see __graft_entry__.load_package()).
 """
-from . import orbx, shard  # noqa: F401
+from . import orbx, shard, streams  # noqa: F401
 from .orbx import Context, OrbxError, default_params  # noqa: F401

@@ -32,8 +32,11 @@ struct DevBuf {
 
 // result block of a batch: one device allocation + one pinned host mirror so
 // a whole batch comes back with a single D2H copy
+// sections: counts | kp | angle | desc || lkp | resp | level -- what the reference's own output consists of
+// (keypoints, orientations, descriptors: include/orb.hpp:37) first, so that orbx_batch_prefetch_compact moves one
+// contiguous prefix of `compact` bytes
 struct OutLayout {
-  size_t counts, kp, lkp, angle, resp, level, desc, total;
+  size_t counts, kp, lkp, angle, resp, level, desc, compact, total;
 };
 
 OutLayout make_out_layout(int n, int cap) {
@@ -47,11 +50,12 @@ OutLayout make_out_layout(int n, int cap) {
   const size_t e = (size_t)n * (size_t)cap;
   o.counts = take(sizeof(int32_t) * (size_t)n);
   o.kp = take(sizeof(orbx_keypoint) * e);
-  o.lkp = take(sizeof(orbx_keypoint) * e);
   o.angle = take(sizeof(float) * e);
+  o.desc = take(sizeof(orbx_descriptor) * e);
+  o.compact = off;
+  o.lkp = take(sizeof(orbx_keypoint) * e);
   o.resp = take(sizeof(float) * e);
   o.level = take(sizeof(int32_t) * e);
-  o.desc = take(sizeof(orbx_descriptor) * e);
   o.total = off;
   return o;
 }
@@ -135,6 +139,7 @@ struct orbx_ctx {
   int nb[2] = {0, 0};    // frames in the block (0: never written)
   int capb[2] = {1, 1};  // slots per frame the block was written with
   bool copy_pending[2] = {false, false};  // an asynchronous D2H of the block has been enqueued (ev_copied)
+  bool copy_compact[2] = {false, false};  // ... of its compact prefix only (orbx_batch_prefetch_compact)
   int blk = 0;
   hipStream_t cstream = nullptr;
   hipEvent_t ev_done[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
@@ -157,6 +162,12 @@ struct orbx_ctx {
   };
   LanePool lane_pool[2];
   hipStream_t lane_stream[2] = {nullptr, nullptr};
+  // Stream order is the only ordering inside a lane.  A batch that comes to a lane's pools, or to a result block,
+  // on ANOTHER stream than their previous user (a caller's stream, the other lane) first makes its stream wait for
+  // that user's event: ev_pool[k] / pool_stream[k] for the pools of lane k, ev_done[b] / blk_stream[b] for block b.
+  hipEvent_t ev_pool[2] = {nullptr, nullptr};
+  hipStream_t pool_stream[2] = {nullptr, nullptr};
+  hipStream_t blk_stream[2] = {nullptr, nullptr};
   bool pipelined = false;
   int last_n = 0;
   bool last_two_pass = false;  // the last batch built its pyramid top rows first (enqueue_batch)
@@ -237,8 +248,10 @@ int fail(orbx_ctx* c, int status, const std::string& msg) {
 
 int ensure(orbx_ctx* c, DevBuf& b, size_t bytes) {
   if (b.bytes >= bytes && b.p) return ORBX_OK;
-  if (b.p) {
+  if (b.p) {  // nothing in flight may still use the old allocation: the context's stream, both lanes, a caller's stream
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (hipStream_t ls : c->lane_stream)
+      if (ls && ls != c->stream) HIPCHK(c, hipStreamSynchronize(ls));
     if (c->last_stream && c->last_stream != c->stream) HIPCHK(c, hipStreamSynchronize(c->last_stream));
     HIPCHK(c, hipFree(b.p));
     b.p = nullptr;
@@ -824,7 +837,11 @@ bool top_rows_wanted(const orbx_ctx* c) {
 // adaptive mode: look at the totals the second passes have reported so far (no waiting: whatever has arrived)
 void top_rows_update(orbx_ctx* c) {
   if (c->top_mode != 2 || !c->h_feedback) return;
-  const uint32_t sk = c->h_feedback[0], pr = c->h_feedback[1];
+  // ONE 64-bit load of the pinned pair (the device writes it as one 8-byte store of two lanes' dwords at best: a torn
+  // or stale pair, or a low half that has wrapped, only misleads this heuristic for one batch -- results never
+  // depend on it)
+  const uint64_t both = *reinterpret_cast<const volatile uint64_t*>(c->h_feedback);
+  const uint32_t sk = (uint32_t)both, pr = (uint32_t)(both >> 32);
   const uint32_t dsk = sk - c->feedback_seen[0], dpr = pr - c->feedback_seen[1];
   if (dsk + dpr > 0) {
     c->feedback_seen[0] = sk;
@@ -950,8 +967,8 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   // pools, own stream, so nothing of the other lane's batch in flight is touched.  (The plan's tables are shared:
   // set_plan waits for both lanes before it changes them.)
   const bool lanes = may_pipeline && c->pipelined && s == c->stream && w == c->plan_w && h == c->plan_h;
+  const int lane = lanes ? (c->blk ^ 1) : 0;
   if (lanes) {
-    const int lane = c->blk ^ 1;
     use_lane(c, lane);
     s = c->lane_stream[lane];
   } else {
@@ -968,9 +985,26 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   // asynchronous D2H copy (orbx_batch_prefetch two batches ago), the kernels wait for the copy
   const int blk = c->blk ^ 1;
   if (c->copy_pending[blk]) HIPCHK(c, hipStreamWaitEvent(s, c->ev_copied[blk], 0));
-  c->blk = blk;
-  c->d_out = c->d_outb[blk];
+  // the previous users of this lane's pools and of this result block, if they ran on another stream (a batch on a
+  // caller's stream between pipelined batches, or the other way round): device-side waits, no host stall
+  if (c->pool_stream[lane] && c->pool_stream[lane] != s) HIPCHK(c, hipStreamWaitEvent(s, c->ev_pool[lane], 0));
+  if (c->blk_stream[blk] && c->blk_stream[blk] != s) HIPCHK(c, hipStreamWaitEvent(s, c->ev_done[blk], 0));
+  // The block becomes "the last batch" only once its launches are enqueued: after a failed call orbx_batch_fetch
+  // must not hand out what an older batch left in it.
+  c->nb[blk] = 0;
+  c->copy_pending[blk] = false;
+  c->copy_compact[blk] = false;
+  uint8_t* const prev_d_out = c->d_out;
+  uint8_t* const prev_h_out = c->h_out;
+  const OutLayout prev_layout = c->out_layout;
+  c->d_out = c->d_outb[blk];  // (enqueue_batch writes through c->d_out)
   c->h_out = c->h_outb[blk];
+  auto fail_restore = [&](int status) {
+    c->d_out = prev_d_out;
+    c->h_out = prev_h_out;
+    c->out_layout = prev_layout;
+    return status;
+  };
   static const int use_graph = [] {
     const char* e = getenv("ORBX_GRAPH");
     return e ? atoi(e) : 1;
@@ -987,24 +1021,29 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
       c->g_next = (c->g_next + 1) % orbx_ctx::kGraphs;
       drop_graph(c, gi);
       hipGraph_t g = nullptr;
-      HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      const hipError_t be = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+      if (be != hipSuccess) return fail_restore(fail(c, ORBX_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(be)));
       st = enqueue_batch(c, d_frames, n, row_stride, frame_stride, s);
       const hipError_t ee = hipStreamEndCapture(s, &g);
       if (st != ORBX_OK) {
         if (g) (void)hipGraphDestroy(g);
-        return st;
+        return fail_restore(st);
       }
-      HIPCHK(c, ee);
+      if (ee != hipSuccess) return fail_restore(fail(c, ORBX_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ee)));
       const hipError_t ie = hipGraphInstantiate(&c->g_exec[gi], g, nullptr, nullptr, 0);
       (void)hipGraphDestroy(g);
-      if (ie != hipSuccess) c->g_exec[gi] = nullptr;
-      HIPCHK(c, ie);
+      if (ie != hipSuccess) {
+        c->g_exec[gi] = nullptr;
+        return fail_restore(fail(c, ORBX_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)));
+      }
       c->g_key[gi] = key;
     }
-    HIPCHK(c, hipGraphLaunch(c->g_exec[gi], s));
+    const hipError_t le = hipGraphLaunch(c->g_exec[gi], s);
+    if (le != hipSuccess) return fail_restore(fail(c, ORBX_ERR_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(le)));
   } else {
-    if ((st = enqueue_batch(c, d_frames, n, row_stride, frame_stride, s)) != ORBX_OK) return st;
+    if ((st = enqueue_batch(c, d_frames, n, row_stride, frame_stride, s)) != ORBX_OK) return fail_restore(st);
   }
+  c->blk = blk;
   c->out_layout = make_out_layout(n, c->plan.out_cap > 0 ? c->plan.out_cap : 1);
   c->last_n = n;
   c->last_stream = s;
@@ -1013,6 +1052,9 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   c->capb[blk] = c->plan.out_cap > 0 ? c->plan.out_cap : 1;
   c->copy_pending[blk] = false;
   HIPCHK(c, hipEventRecord(c->ev_done[blk], s));
+  HIPCHK(c, hipEventRecord(c->ev_pool[lane], s));
+  c->pool_stream[lane] = s;
+  c->blk_stream[blk] = s;
   if (tm != 0) {
     c->ev_mode[c->ev_calls % ORBX_EVENT_SETS] = tm;
     c->ev_calls++;
@@ -1125,21 +1167,28 @@ const char* orbx_version(void) { return "liborbx 0.1.0 gfx950"; }
 
 const char* orbx_last_error_string(const orbx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+namespace {
+// the second lane's pools and stream (nothing of it may be in flight)
+void free_lane1(orbx_ctx* c) {
+  orbx_ctx::LanePool& L = c->lane_pool[1];
+  void* lb[] = {L.d_pyr, L.d_pyr_blur, L.d_mask, L.d_row_stat, L.d_cand, L.d_cand_count, L.d_cand_total, L.d_resp,
+                L.d_lcand, L.d_lresp, L.d_lcount};
+  for (void* b : lb)
+    if (b) (void)hipFree(b);
+  L = orbx_ctx::LanePool{};
+  if (c->lane_stream[1]) (void)hipStreamDestroy(c->lane_stream[1]);
+  c->lane_stream[1] = nullptr;
+  c->pool_stream[1] = nullptr;
+}
+}  // namespace
+
 void orbx_destroy(orbx_ctx* c) {
   DeviceGuard _dg(c);
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  if (c->lane_stream[1]) {  // the second lane of the pipelined mode
-    (void)hipStreamSynchronize(c->lane_stream[1]);
-    use_lane(c, 0);  // (the list below frees the context's own pools)
-    const orbx_ctx::LanePool& L = c->lane_pool[1];
-    void* lb[] = {L.d_pyr, L.d_pyr_blur, L.d_mask, L.d_row_stat, L.d_cand, L.d_cand_count, L.d_cand_total, L.d_resp,
-                  L.d_lcand, L.d_lresp, L.d_lcount};
-    for (void* b : lb)
-      if (b) (void)hipFree(b);
-    (void)hipStreamDestroy(c->lane_stream[1]);
-    c->lane_stream[1] = nullptr;
-  }
+  if (c->lane_stream[1]) (void)hipStreamSynchronize(c->lane_stream[1]);
+  use_lane(c, 0);  // (the list below frees the context's own pools)
+  free_lane1(c);   // the second lane of the pipelined mode (also what a failed enable left behind)
   for (int i = 0; i < orbx_ctx::kGraphs; i++) drop_graph(c, i);
   void* bufs[] = {c->d_in,   c->d_pyr,  c->d_pyr_blur, c->d_mask, c->d_cand, c->d_cand_count, c->d_cand_total,
                   c->d_resp, c->d_taps, c->d_gauss,    c->d_row_stat, c->d_tiles_fast, c->d_tiles_blur, c->d_tiles_pyr2, c->d_tiles_pyrblur, c->d_tiles_pyrblur_small,
@@ -1152,6 +1201,7 @@ void orbx_destroy(orbx_ctx* c) {
     if (c->d_outb[i]) (void)hipFree(c->d_outb[i]);
     if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
     if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
+    if (c->ev_pool[i]) (void)hipEventDestroy(c->ev_pool[i]);
   }
   if (c->cstream) {
     (void)hipStreamSynchronize(c->cstream);
@@ -1290,6 +1340,7 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
       CREATE_CHK(hipHostMalloc((void**)&c->h_outb[i], o.total, hipHostMallocDefault));
       CREATE_CHK(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
       CREATE_CHK(hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
+      CREATE_CHK(hipEventCreateWithFlags(&c->ev_pool[i], hipEventDisableTiming));
     }
     c->d_out = c->d_outb[0];
     c->h_out = c->h_outb[0];
@@ -1384,21 +1435,28 @@ int orbx_set_pipelined_batches(orbx_ctx* c, int enable) {
     const OrbxPlan& M = c->plan_max;
     const size_t B = (size_t)p->max_batch;
     orbx_ctx::LanePool& L = c->lane_pool[1];
-    HIPCHK(c, hipMalloc((void**)&L.d_pyr, B * (size_t)M.frame_bytes + 256));
-    if (p->blur_levels != ORBX_BLUR_NONE) {
-      HIPCHK(c, hipMalloc((void**)&L.d_pyr_blur, B * (size_t)M.frame_bytes + 256));
-      HIPCHK(c, hipMemset(L.d_pyr_blur, 0, B * (size_t)M.frame_bytes));  // (the padding bytes of a level stay zero)
+    const size_t nc = (size_t)std::max(M.cand_total, 1);
+    hipError_t e = hipMalloc((void**)&L.d_pyr, B * (size_t)M.frame_bytes + 256);
+    if (e == hipSuccess && p->blur_levels != ORBX_BLUR_NONE) {
+      e = hipMalloc((void**)&L.d_pyr_blur, B * (size_t)M.frame_bytes + 256);
+      if (e == hipSuccess) e = hipMemset(L.d_pyr_blur, 0, B * (size_t)M.frame_bytes);  // (the padding bytes of a level stay zero)
     }
-    HIPCHK(c, hipMalloc((void**)&L.d_mask, B * (size_t)M.mask_words * 8 + 256));
-    HIPCHK(c, hipMalloc((void**)&L.d_row_stat, B * ORBX_FAST_STAT_WORDS * 8));
-    HIPCHK(c, hipMalloc((void**)&L.d_cand, B * (size_t)std::max(M.cand_total, 1) * sizeof(orbx_keypoint)));
-    HIPCHK(c, hipMalloc((void**)&L.d_cand_count, B * ORBX_MAX_LEVELS * sizeof(int32_t)));
-    HIPCHK(c, hipMalloc((void**)&L.d_cand_total, B * ORBX_MAX_LEVELS * sizeof(int32_t)));
-    HIPCHK(c, hipMalloc((void**)&L.d_resp, B * (size_t)std::max(M.cand_total, 1) * sizeof(float)));
-    HIPCHK(c, hipMalloc((void**)&L.d_lcand, B * (size_t)std::max(M.cand_total, 1) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&L.d_lresp, B * (size_t)std::max(M.cand_total, 1) * sizeof(float)));
-    HIPCHK(c, hipMalloc((void**)&L.d_lcount, B * ORBX_MAX_LEVELS * sizeof(int32_t)));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->lane_stream[1], hipStreamNonBlocking));
+    if (e == hipSuccess) e = hipMalloc((void**)&L.d_mask, B * (size_t)M.mask_words * 8 + 256);
+    if (e == hipSuccess) e = hipMemset(L.d_mask, 0, B * (size_t)M.mask_words * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&L.d_row_stat, B * ORBX_FAST_STAT_WORDS * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&L.d_cand, B * nc * sizeof(orbx_keypoint));
+    if (e == hipSuccess) e = hipMalloc((void**)&L.d_cand_count, B * ORBX_MAX_LEVELS * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&L.d_cand_total, B * ORBX_MAX_LEVELS * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&L.d_resp, B * nc * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&L.d_lcand, B * nc * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&L.d_lresp, B * nc * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&L.d_lcount, B * ORBX_MAX_LEVELS * sizeof(int32_t));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->lane_stream[1], hipStreamNonBlocking);
+    if (e != hipSuccess) {  // (at batch 512 the second pool set is GBs: running out of memory is the realistic failure)
+      free_lane1(c);
+      c->pipelined = false;
+      return fail(c, ORBX_ERR_HIP, std::string("second lane of the pipelined mode: ") + hipGetErrorString(e));
+    }
   }
   c->pipelined = enable != 0;
   return ORBX_OK;
@@ -1539,7 +1597,14 @@ int fetch_block(orbx_ctx* c, int b, int first, int n, int32_t* counts, orbx_keyp
   const OutLayout& o = c->layoutb[b];
   const int cap = c->capb[b];
   const uint8_t* h = c->h_outb[b];
-  if (c->copy_pending[b]) {
+  if (c->copy_pending[b] && c->copy_compact[b] && (responses || levels || level_kps)) {
+    // only the compact prefix is on its way: fetch the other sections now (blocking)
+    HIPCHK(c, hipEventSynchronize(c->ev_copied[b]));
+    HIPCHK(c, hipMemcpyAsync(c->h_outb[b] + o.compact, c->d_outb[b] + o.compact, o.total - o.compact, hipMemcpyDeviceToHost,
+                             c->cstream));
+    HIPCHK(c, hipStreamSynchronize(c->cstream));
+    c->copy_compact[b] = false;
+  } else if (c->copy_pending[b]) {
     HIPCHK(c, hipEventSynchronize(c->ev_copied[b]));
   } else if (b == c->blk) {
     // blocking fetch of the last batch: the copy goes behind the batch on ITS stream (no hop to the copy
@@ -1599,29 +1664,52 @@ int orbx_batch_results_host(orbx_ctx* c, int previous, orbx_batch_view* v) {
     HIPCHK(c, hipEventSynchronize(c->ev_copied[b]));
   }
   const uint8_t* h = c->h_outb[b];
+  const bool compact = c->copy_compact[b];  // (those sections of the mirror were not copied: NULL in the view)
   v->counts = (const int32_t*)(h + o.counts);
   v->keypoints = (const orbx_keypoint*)(h + o.kp);
-  v->level_kps = (const orbx_keypoint*)(h + o.lkp);
+  v->level_kps = compact ? nullptr : (const orbx_keypoint*)(h + o.lkp);
   v->orientations = (const float*)(h + o.angle);
-  v->responses = (const float*)(h + o.resp);
-  v->levels = (const int32_t*)(h + o.level);
+  v->responses = compact ? nullptr : (const float*)(h + o.resp);
+  v->levels = compact ? nullptr : (const int32_t*)(h + o.level);
   v->descriptors = (const orbx_descriptor*)(h + o.desc);
   v->slot_capacity = c->capb[b];
   v->n = c->nb[b];
   return ORBX_OK;
 }
 
+namespace {
+int prefetch_block(orbx_ctx* c, bool compact) {
+  const int b = c->blk;
+  if (c->nb[b] <= 0) return fail(c, ORBX_ERR_INVALID_ARG, "no batch has been run");
+  const OutLayout& o = c->layoutb[b];
+  if (c->copy_pending[b]) {
+    if (compact || !c->copy_compact[b]) return ORBX_OK;
+    // a compact copy is on its way and the whole block is wanted after all: the other sections follow it
+    HIPCHK(c, hipMemcpyAsync(c->h_outb[b] + o.compact, c->d_outb[b] + o.compact, o.total - o.compact, hipMemcpyDeviceToHost,
+                             c->cstream));
+    HIPCHK(c, hipEventRecord(c->ev_copied[b], c->cstream));
+    c->copy_compact[b] = false;
+    return ORBX_OK;
+  }
+  HIPCHK(c, hipStreamWaitEvent(c->cstream, c->ev_done[b], 0));
+  HIPCHK(c, hipMemcpyAsync(c->h_outb[b], c->d_outb[b], compact ? o.compact : o.total, hipMemcpyDeviceToHost, c->cstream));
+  HIPCHK(c, hipEventRecord(c->ev_copied[b], c->cstream));
+  c->copy_pending[b] = true;
+  c->copy_compact[b] = compact;
+  return ORBX_OK;
+}
+}  // namespace
+
 int orbx_batch_prefetch(orbx_ctx* c) {
   DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
-  const int b = c->blk;
-  if (c->nb[b] <= 0) return fail(c, ORBX_ERR_INVALID_ARG, "no batch has been run");
-  if (c->copy_pending[b]) return ORBX_OK;
-  HIPCHK(c, hipStreamWaitEvent(c->cstream, c->ev_done[b], 0));
-  HIPCHK(c, hipMemcpyAsync(c->h_outb[b], c->d_outb[b], c->layoutb[b].total, hipMemcpyDeviceToHost, c->cstream));
-  HIPCHK(c, hipEventRecord(c->ev_copied[b], c->cstream));
-  c->copy_pending[b] = true;
-  return ORBX_OK;
+  return prefetch_block(c, false);
+}
+
+int orbx_batch_prefetch_compact(orbx_ctx* c) {
+  DeviceGuard _dg(c);
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  return prefetch_block(c, true);
 }
 
 int orbx_batch_fetch_previous(orbx_ctx* c, int first, int n, int32_t* counts, orbx_keypoint* keypoints,
@@ -2080,6 +2168,8 @@ int orbx_batch_match_consecutive(orbx_ctx* c, double ratio) {
   DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
   if (c->last_n < 2) return fail(c, ORBX_ERR_INVALID_ARG, "needs a batch of at least two frames");
+  // the match buffers are ONE set per context: a match of the other lane's batch may still be writing them
+  if (c->lane_stream[1]) HIPCHK(c, lanes_sync(c));
   const int n = c->last_n, cap = c->plan.out_cap > 0 ? c->plan.out_cap : 1;
   const size_t e = (size_t)(n - 1) * cap;
   int st;

@@ -27,7 +27,7 @@ EXPORTS = [
     "orbx_params_default_gpu", "orbx_params_default_cpu", "orbx_create", "orbx_destroy",
     "orbx_last_error_string", "orbx_status_string", "orbx_version", "orbx_get_plan",
     "orbx_detect_and_compute", "orbx_detect_and_compute_batch_device", "orbx_detect_and_compute_batch_host",
-    "orbx_wait", "orbx_batch_results_device", "orbx_batch_results_host", "orbx_batch_fetch", "orbx_batch_prefetch",
+    "orbx_wait", "orbx_batch_results_device", "orbx_batch_results_host", "orbx_batch_fetch", "orbx_batch_prefetch", "orbx_batch_prefetch_compact",
     "orbx_batch_fetch_previous", "orbx_enable_stage_timing",
     "orbx_last_stage_times", "orbx_stage_times_history", "orbx_bench_stage", "orbx_set_fast_early_exit",
     "orbx_set_fused_pyramid_blur", "orbx_set_top_rows_first", "orbx_set_pipelined_batches", "orbx_fast_tile_counts", "orbx_pyramid_pixel_counts", "orbx_lk_track", "orbx_lk_pyramid_levels", "orbx_fast_score", "orbx_nms", "orbx_fast",
@@ -246,6 +246,8 @@ class Context:
         n, cap = v.n, v.slot_capacity
 
         def arr(ptr, dtype, shape):
+            if not ptr:  # (a section a compact prefetch did not copy)
+                return None
             size = int(np.prod(shape)) * np.dtype(dtype).itemsize
             return np.frombuffer((C.c_char * size).from_address(ptr), dtype=dtype).reshape(shape)
 
@@ -254,9 +256,13 @@ class Context:
                     responses=arr(v.responses, np.float32, (n, cap)), levels=arr(v.levels, np.int32, (n, cap)),
                     desc=arr(v.descriptors, np.uint8, (n, cap, 32)))
 
-    def batch_prefetch(self):
-        """Start the asynchronous D2H copy of the last batch's result block (overlaps the next batch)."""
-        self._chk(self._lib.orbx_batch_prefetch(self._h))
+    def batch_prefetch(self, compact=False):
+        """Start the asynchronous D2H copy of the last batch's result block (overlaps the next batch); compact: only
+        counts, keypoints, orientations and descriptors (orbx_batch_prefetch_compact)."""
+        if compact:
+            self._chk(self._lib.orbx_batch_prefetch_compact(self._h))
+        else:
+            self._chk(self._lib.orbx_batch_prefetch(self._h))
 
     def batch_fetch(self, first, n, capacity, previous=False):
         """Results of the last batch (previous=True: of the batch before it, see orbx_batch_fetch_previous)."""
