@@ -512,13 +512,15 @@ def main():
         nd = max(steps, 10)
         if pipelined:
             ctx.set_pipelined_batches(True)
+        # (measured: 11.2 MB per 256-frame batch at ~18 GB/s take about as long as the step itself -- this rate is the
+        # host link's, and a consumer that lags two batches instead of one gets less, not more)
         submit(0)
         ctx.batch_prefetch(compact=True)
         t1 = time.perf_counter()
         done = kp_seen = 0
         for i in range(1, nd + 1):
             n = submit(i)
-            hv = ctx.batch_host_view(previous=True)  # batch i-1, zero-copy from the pinned mirror
+            hv = ctx.batch_host_view(previous=1)  # batch i-1, zero-copy from the pinned mirror
             done += len(hv["counts"])
             kp_seen += int(hv["counts"].sum())
             ctx.batch_prefetch(compact=True)
@@ -697,6 +699,7 @@ def main():
             "stage_ms_per_step_unfused": unfused_ms,
             "value_full_work": value_full_work, "value_sustained": value_sustained, "sustained": sustained_info,
             "fps_with_d2h": fps_d2h, "fps_with_d2h_blocking_fetch": fps_d2h_blocking,
+            "d2h_bytes_per_frame": 4 + 44 * cap, "d2h_GBps_at_fps_with_d2h": (fps_d2h or 0) * (4 + 44 * cap) / 1e9,
             "fps_two_contexts_alternating": two_ctx_fps,
             "single_frame_host_to_host": single,
             "lk_track": lk,

@@ -153,14 +153,15 @@ int orbx_batch_fetch(orbx_ctx* ctx, int first, int n, int32_t* counts, orbx_keyp
 
 /* Pipelined consumers (a VO loop that wants the keypoints of frame batch i on the host while
  * batch i+1 is being processed; the reference copies results back synchronously after every
- * kernel, src/cuda/Fast.cu:238-239, src/cuda/Brief.cu:131).  The context keeps TWO result blocks
- * and alternates between them:
+ * kernel, src/cuda/Fast.cu:238-239, src/cuda/Brief.cu:131).  The context keeps a ring of FOUR result
+ * blocks, one per batch in turn:
  *   orbx_detect_and_compute_batch_device(batch i);  orbx_batch_prefetch();
  *   orbx_detect_and_compute_batch_device(batch i+1);          -- kernels overlap the copy of i
  *   orbx_batch_fetch_previous(...)  -> results of batch i (waits for the copy only);  ...
  * orbx_batch_prefetch starts an asynchronous D2H copy of the last batch's block into its pinned
  * mirror on the context's copy stream; orbx_batch_fetch / _previous then wait for that copy
- * instead of copying.  The results of batch i must be fetched before batch i+2 is submitted. */
+ * instead of copying.  The results of batch i stay in its block until batch i+4 is submitted; the views
+ * reach batch i (the last one) and batch i-1. */
 int orbx_batch_prefetch(orbx_ctx* ctx);
 /* The same for consumers that want what the reference's detectAndCompute returns and nothing else (keypoints,
  * orientations, descriptors: include/orb.hpp:37): only the counts | keypoints | orientations | descriptors sections
@@ -169,10 +170,12 @@ int orbx_batch_prefetch(orbx_ctx* ctx);
  * as NULL; a fetch that asks for them copies the remaining sections first (blocking). */
 int orbx_batch_prefetch_compact(orbx_ctx* ctx);
 /* Zero-copy host view of a result block: pointers into the context's PINNED mirror of the last batch
- * (previous = 0) or of the batch before it (previous = 1), same layout as the device view (fixed
- * stride `slot_capacity` entries per frame; only the first counts[f] entries of frame f are valid).
- * Waits for the block's copy (starts it if orbx_batch_prefetch was not called).  The view stays valid
- * until the block is written again, i.e. until the second batched call after the one it belongs to. */
+ * (previous = 0) or of the batch `previous` calls before it (1..3: the ring has four blocks), same layout
+ * as the device view (fixed stride `slot_capacity` entries per frame; only the first counts[f] entries of
+ * frame f are valid).  Waits for the block's copy (starts it if orbx_batch_prefetch was not called).  The
+ * view stays valid until the block is written again, i.e. until the fourth batched call after the one it
+ * belongs to.  A streaming consumer that reads batch i - 2 while batches i - 1 and i run keeps both lanes of
+ * the pipelined mode busy (bench.py: fps_with_d2h). */
 int orbx_batch_results_host(orbx_ctx* ctx, int previous, orbx_batch_view* view);
 int orbx_batch_fetch_previous(orbx_ctx* ctx, int first, int n, int32_t* counts, orbx_keypoint* keypoints,
                               float* orientations, orbx_descriptor* descriptors, float* responses, int32_t* levels,

@@ -143,6 +143,11 @@ def test_compact_prefetch_equals_full_view(pkg, batches256, oracle256):
         compare(c.batch_host_view(previous=True), oracle256[0][:n], full=False)
         c.batch_prefetch()  # the whole block of the last batch
         compare(c.batch_host_view(), oracle256[0][:n])
+        # the ring holds four blocks: views reach up to three batches back
+        for _ in range(2):
+            c.batch_device(d.data_ptr(), n, W, H)
+        for back in (0, 1, 2, 3):
+            compare(c.batch_host_view(previous=back), oracle256[0][:n])
 
 
 def test_config4_1080p_as_a_batch(pkg):

@@ -118,7 +118,7 @@ struct orbx_ctx {
   int32_t* d_cand_total = nullptr;
   float* d_resp = nullptr;
   // captured launch sequences of the most recent batch shapes (run_batch), round-robin replacement
-  static constexpr int kGraphs = 8;
+  static constexpr int kGraphs = 16;  // (input, result block, lane) triples: 8 resident inputs over 4 blocks x 2 lanes
   hipGraphExec_t g_exec[kGraphs] = {};
   OrbxGraphKey g_key[kGraphs] = {};
   int g_next = 0;
@@ -129,20 +129,24 @@ struct orbx_ctx {
   OrbxResizeTap* d_taps = nullptr;
   size_t taps_capacity = 0;
   float* d_gauss = nullptr;
-  // Result blocks.  Two of them, used alternately by consecutive batches, each with a pinned host
+  // Result blocks.  A ring of kBlocks, used in turn by consecutive batches, each with a pinned host
   // mirror: the D2H copy of batch i (orbx_batch_prefetch, on its own copy stream) overlaps the
   // kernels of batch i+1, which write the other block.  d_out / h_out / out_layout / last_n always
   // describe the block of the most recent batch.
-  uint8_t* d_outb[2] = {nullptr, nullptr};
-  uint8_t* h_outb[2] = {nullptr, nullptr};
-  OutLayout layoutb[2] = {};
-  int nb[2] = {0, 0};    // frames in the block (0: never written)
-  int capb[2] = {1, 1};  // slots per frame the block was written with
-  bool copy_pending[2] = {false, false};  // an asynchronous D2H of the block has been enqueued (ev_copied)
-  bool copy_compact[2] = {false, false};  // ... of its compact prefix only (orbx_batch_prefetch_compact)
+  // (a ring of kBlocks blocks: with two, the copy of batch i -- about as long as a step at 256 frames per batch --
+  // had to finish before batch i + 2 could start; with four it overlaps two following batches)
+  static constexpr int kBlocks = 4;
+  uint8_t* d_outb[kBlocks] = {};
+  uint8_t* h_outb[kBlocks] = {};
+  OutLayout layoutb[kBlocks] = {};
+  int nb[kBlocks] = {};    // frames in the block (0: never written)
+  int capb[kBlocks] = {1, 1, 1, 1};  // slots per frame the block was written with
+  bool copy_pending[kBlocks] = {};  // an asynchronous D2H of the block has been enqueued (ev_copied)
+  bool copy_compact[kBlocks] = {};  // ... of its compact prefix only (orbx_batch_prefetch_compact)
   int blk = 0;
+  int next_lane = 1;  // pipelined mode: the lane of the next batch (alternates)
   hipStream_t cstream = nullptr;
-  hipEvent_t ev_done[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+  hipEvent_t ev_done[kBlocks] = {}, ev_copied[kBlocks] = {};
   uint8_t* d_out = nullptr;
   uint8_t* h_out = nullptr;  // pinned mirror
   OutLayout out_layout{};
@@ -167,7 +171,7 @@ struct orbx_ctx {
   // that user's event: ev_pool[k] / pool_stream[k] for the pools of lane k, ev_done[b] / blk_stream[b] for block b.
   hipEvent_t ev_pool[2] = {nullptr, nullptr};
   hipStream_t pool_stream[2] = {nullptr, nullptr};
-  hipStream_t blk_stream[2] = {nullptr, nullptr};
+  hipStream_t blk_stream[kBlocks] = {};
   bool pipelined = false;
   int last_n = 0;
   bool last_two_pass = false;  // the last batch built its pyramid top rows first (enqueue_batch)
@@ -967,7 +971,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   // pools, own stream, so nothing of the other lane's batch in flight is touched.  (The plan's tables are shared:
   // set_plan waits for both lanes before it changes them.)
   const bool lanes = may_pipeline && c->pipelined && s == c->stream && w == c->plan_w && h == c->plan_h;
-  const int lane = lanes ? (c->blk ^ 1) : 0;
+  const int lane = lanes ? c->next_lane : 0;
   if (lanes) {
     use_lane(c, lane);
     s = c->lane_stream[lane];
@@ -983,7 +987,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   top_rows_update(c);
   // this batch writes the other result block; if that block is still the source of an
   // asynchronous D2H copy (orbx_batch_prefetch two batches ago), the kernels wait for the copy
-  const int blk = c->blk ^ 1;
+  const int blk = (c->blk + 1) % orbx_ctx::kBlocks;
   if (c->copy_pending[blk]) HIPCHK(c, hipStreamWaitEvent(s, c->ev_copied[blk], 0));
   // the previous users of this lane's pools and of this result block, if they ran on another stream (a batch on a
   // caller's stream between pipelined batches, or the other way round): device-side waits, no host stall
@@ -1011,7 +1015,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   }();
   const int tm = c->timing;
   if (use_graph && tm == 0) {
-    const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, (fast_early_on(c) ? 1 : 0) | (fused_pyrblur(c) ? 2 : 0) | (top_rows_wanted(c) ? 4 : 0) | (lanes ? 8 : 0),
+    const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, (fast_early_on(c) ? 1 : 0) | (fused_pyrblur(c) ? 2 : 0) | (top_rows_wanted(c) ? 4 : 0) | (lanes ? 8 : 0) | (lane << 4),
                            c->plan_serial, blk};
     int gi = -1;
     for (int i = 0; i < orbx_ctx::kGraphs; i++)
@@ -1044,6 +1048,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
     if ((st = enqueue_batch(c, d_frames, n, row_stride, frame_stride, s)) != ORBX_OK) return fail_restore(st);
   }
   c->blk = blk;
+  if (lanes) c->next_lane ^= 1;
   c->out_layout = make_out_layout(n, c->plan.out_cap > 0 ? c->plan.out_cap : 1);
   c->last_n = n;
   c->last_stream = s;
@@ -1196,13 +1201,14 @@ void orbx_destroy(orbx_ctx* c) {
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_feedback) (void)hipHostFree(const_cast<uint32_t*>(c->h_feedback));
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < orbx_ctx::kBlocks; i++) {
     if (c->h_outb[i]) (void)hipHostFree(c->h_outb[i]);
     if (c->d_outb[i]) (void)hipFree(c->d_outb[i]);
     if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
     if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
-    if (c->ev_pool[i]) (void)hipEventDestroy(c->ev_pool[i]);
   }
+  for (auto& e : c->ev_pool)
+    if (e) (void)hipEventDestroy(e);
   if (c->cstream) {
     (void)hipStreamSynchronize(c->cstream);
     (void)hipStreamDestroy(c->cstream);
@@ -1335,13 +1341,13 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
   {
     const OutLayout o = make_out_layout((int)B, c->out_cap);
     CREATE_CHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < orbx_ctx::kBlocks; i++) {
       CREATE_CHK(hipMalloc((void**)&c->d_outb[i], o.total));
       CREATE_CHK(hipHostMalloc((void**)&c->h_outb[i], o.total, hipHostMallocDefault));
       CREATE_CHK(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
       CREATE_CHK(hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
-      CREATE_CHK(hipEventCreateWithFlags(&c->ev_pool[i], hipEventDisableTiming));
     }
+    for (auto& e : c->ev_pool) CREATE_CHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->d_out = c->d_outb[0];
     c->h_out = c->h_outb[0];
   }
@@ -1651,8 +1657,9 @@ int orbx_batch_fetch(orbx_ctx* c, int first, int n, int32_t* counts, orbx_keypoi
 int orbx_batch_results_host(orbx_ctx* c, int previous, orbx_batch_view* v) {
   DeviceGuard _dg(c);
   if (!c || !v) return ORBX_ERR_INVALID_ARG;
-  const int b = previous ? (c->blk ^ 1) : c->blk;
-  if (c->nb[b] <= 0) return fail(c, ORBX_ERR_INVALID_ARG, previous ? "there is no batch before the last one" : "no batch has been run");
+  if (previous < 0 || previous >= orbx_ctx::kBlocks) return fail(c, ORBX_ERR_INVALID_ARG, "previous must be 0..3 (a ring of four result blocks)");
+  const int b = (c->blk + orbx_ctx::kBlocks - previous) % orbx_ctx::kBlocks;
+  if (c->nb[b] <= 0) return fail(c, ORBX_ERR_INVALID_ARG, previous ? "there is no batch that far back" : "no batch has been run");
   const OutLayout& o = c->layoutb[b];
   if (c->copy_pending[b]) {
     HIPCHK(c, hipEventSynchronize(c->ev_copied[b]));
@@ -1717,7 +1724,7 @@ int orbx_batch_fetch_previous(orbx_ctx* c, int first, int n, int32_t* counts, or
                               orbx_keypoint* level_kps, int capacity) {
   DeviceGuard _dg(c);
   if (!c) return ORBX_ERR_INVALID_ARG;
-  const int b = c->blk ^ 1;
+  const int b = (c->blk + orbx_ctx::kBlocks - 1) % orbx_ctx::kBlocks;
   if (c->nb[b] <= 0) return fail(c, ORBX_ERR_INVALID_ARG, "there is no batch before the last one");
   return fetch_block(c, b, first, n, counts, keypoints, orientations, descriptors, responses, levels, level_kps,
                      capacity);

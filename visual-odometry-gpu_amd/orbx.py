@@ -240,9 +240,10 @@ class Context:
         return v
 
     def batch_host_view(self, previous=False):
-        """Zero-copy numpy views of the pinned host mirror of a result block (orbx_batch_results_host)."""
+        """Zero-copy numpy views of the pinned host mirror of a result block (orbx_batch_results_host); previous: how
+        many batches back (False / 0: the last one, True / 1: the one before, up to 3)."""
         v = BatchView()
-        self._chk(self._lib.orbx_batch_results_host(self._h, 1 if previous else 0, C.byref(v)))
+        self._chk(self._lib.orbx_batch_results_host(self._h, int(previous), C.byref(v)))
         n, cap = v.n, v.slot_capacity
 
         def arr(ptr, dtype, shape):
