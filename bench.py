@@ -9,8 +9,8 @@ Rank 0 prints ONE JSON line.
 Workload (BASELINE.json configs[1], batched as configs[2]): KITTI-shaped 1241x376 8-bit frames,
 8 pyramid levels, scale 1.2, 1000 features, FAST-9 threshold 20, 3x3 NMS, Harris top-N, orientation
 patch 31, rotated BRIEF-256, 5x5 Gaussian blur on every level.  A "step" = one pass of the whole
-path over one batch of --batch (default 256) synthetic frames that are already resident in HBM; the
-steps rotate over --rotate (default 2) DISTINCT resident batches, so the pools of a step (~0.9 GB) and
+path over one batch of --batch (default 1024) synthetic frames that are already resident in HBM; the
+steps rotate over --rotate (default 2) DISTINCT resident batches, so the pools of a step (~3.5 GB) and
 its inputs lie far beyond the 256 MiB Infinity Cache: every kernel streams from and to HBM.  Results stay resident in HBM too
 (the D2H-inclusive rate is reported beside it as `fps_with_d2h`, it is never `value`).  The timed region is the
 production shape: pipelined batches (orbx_set_pipelined_batches: two batches in flight on two lanes of the context),
@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU (resident in HBM)")
+    ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU (resident in HBM)")
     ap.add_argument("--rotate", type=int, default=2, help="distinct resident input batches the steps rotate over")
     ap.add_argument("--workload", default="kitti", choices=["kitti", "1080p"])
     ap.add_argument("--stream-frames", type=int, default=0,
@@ -614,11 +614,16 @@ def main():
                 e["valu_insts_per_launch"] = c.get("valu")
                 if c.get("valu"):
                     e["valu_floor_ms"] = c["valu"] * 4 / N_SIMD / (VALU_CLOCK_GHZ * 1e9) * 1e3
+                if c.get("sq_active_inst_valu") and c.get("sq_busy_cycles"):
+                    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs, SQ_BUSY_CYCLES cycles summed over the
+                    # 32 shader engines: the share of the kernel's cycles in which a SIMD's vector unit was busy
+                    e["valu_busy_frac"] = c["sq_active_inst_valu"] * 4 / N_SIMD / (c["sq_busy_cycles"] / 32)
                 e["hbm_traffic_bytes_per_launch"] = c.get("traffic_bytes")
             if extra:
                 e.update(extra)
             return e
 
+        fast_kernel = "k_fast4" if os.environ.get("ORBX_FAST_IMPL") == "4" else "k_fast3"
         work_frac = fast_tiles[0] / max(fast_tiles[1], 1)
         pyr_frac = pyr_done[0] / max(pyr_done[1], 1)
         fused = not args.unfused
@@ -649,9 +654,9 @@ def main():
             kern["pyramid_alone"] = entry("pyramid", alg["pyramid"], src_ms["pyramid"], "k_pyramid2")
             kern["blur_alone"] = entry("blur", alg["blur"], src_ms["blur"] if fused else roof_ms["blur"], "k_blur3")
         kern.update({
-            "fast_nms_full_work": entry("fast_nms", alg["fast_nms"], full_ms["fast_nms"], "k_fast3_full_work",
+            "fast_nms_full_work": entry("fast_nms", alg["fast_nms"], full_ms["fast_nms"], fast_kernel + "_full_work",
                                         {"tiles_worked": full_tiles[0], "tiles": full_tiles[1]}),
-            "fast_nms_timed_region": entry("fast_nms", alg["fast_nms"] * work_frac, roof_ms["fast_nms"], "k_fast3",
+            "fast_nms_timed_region": entry("fast_nms", alg["fast_nms"] * work_frac, roof_ms["fast_nms"], fast_kernel,
                                            {"tiles_worked": fast_tiles[0], "tiles": fast_tiles[1],
                                             "note": "early exit on (production): bytes charged = tiles that worked / all tiles x 1 B/px"}),
             "select": entry("select", 0, stage_ms["select"] + stage_ms["compact"] + stage_ms["harris"], "k_level_select"),
@@ -679,7 +684,7 @@ def main():
                        "sharding": "frame-parallel, no data-path collective",
                        "fast_early_exit": not args.full_work, "pyramid_blur_fused": not args.unfused,
                        "pyramid_top_rows_first": bool(pyr_done[0] < pyr_done[1]), "pipelined_batches": pipelined},
-            "roofline": {"bound": "hbm", "kernel": "k_blur3 (stand-alone)" if dom == "blur_alone" else "k_fast3 (every tile working)",
+            "roofline": {"bound": "hbm", "kernel": "k_blur3 (stand-alone)" if dom == "blur_alone" else fast_kernel + " (every tile working)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": kern.get(dom, {}).get("hbm_traffic_bytes_per_launch"),
                          "algorithmic_bytes_per_launch": alg["blur"] if dom == "blur_alone" else alg["fast_nms"],
@@ -690,7 +695,7 @@ def main():
                          "blur_plus_fast": {"full_work": {"achieved": both_full, "frac": both_full / HBM_PEAK_GBS},
                                             "timed_region_bytes_touched": {"achieved": both_timed, "frac": both_timed / HBM_PEAK_GBS}},
                          "kernels": kern,
-                         "pmc_counters": "profiles/r02/pmc_counters.json (same kernel sources)" if pmc else None},
+                         "pmc_counters": "profiles/r03/pmc_counters.json (same kernel sources)" if pmc else None},
             "roofline_kernels_ms": roof_ms,
             "fast_tiles": {"full_work": fast_tiles[0], "total": fast_tiles[1], "early_exit_frac": 1.0 - work_frac},
             "pyramid_pixels": {"produced": pyr_done[0], "total": pyr_done[1], "produced_frac": pyr_frac},

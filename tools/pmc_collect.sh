@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 evidence for profiles/r02 (run on the GPU box: bash tools/pmc_collect.sh).
+# rocprofv3 evidence for profiles/r03 (run on the GPU box: bash tools/pmc_collect.sh).
 #   kernel-trace --stats and the PMC passes are SEPARATE runs (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2:
 #   /opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots"); the program after `--` is python3 itself.
 # Configurations of bench.py (--only-timed: nothing but the timed region runs, so the per-kernel averages
@@ -11,9 +11,9 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-O=gpurun_out/r02
+O=gpurun_out/r03c
 mkdir -p $O
-B="bench.py --only-timed --no-cpu-baseline --steps 10 --warmup 2"   # bench.py's default workload: 256 frames per launch
+B="bench.py --only-timed --no-cpu-baseline --steps 6 --warmup 2"   # bench.py's default workload: 1024 frames per launch
 B64="bench.py --only-timed --no-cpu-baseline --batch 64 --rotate 4 --steps 10 --warmup 2"  # BASELINE.json configs[2]
 run() {  # name, rocprof args..., -- bench args
   local name=$1; shift
@@ -35,9 +35,16 @@ for cfg in timed fullwork unfused; do
   run ${cfg}_fetch --kernel-trace --pmc FETCH_SIZE -d $O/${cfg}_fetch -o run --output-format csv -- python3 $B $X
   run ${cfg}_write --kernel-trace --pmc WRITE_SIZE -d $O/${cfg}_write -o run --output-format csv -- python3 $B $X
 done
-# kernel durations at 64 frames per launch (BASELINE.json configs[2]; pools inside the Infinity Cache) and at
-# 512 (pools ~1.8 GB)
-B512="bench.py --only-timed --no-cpu-baseline --batch 512 --rotate 1 --steps 4 --warmup 1"
+# the register-streaming FAST kernel (ORBX_FAST_IMPL=4; the default whole path runs the LDS tile kernel), every tile working
+export ORBX_FAST_IMPL=4
+run fast4_stats --kernel-trace --stats -d $O/fast4_stats -o run --output-format csv -- python3 $B --full-work
+run fast4_sqa --kernel-trace --pmc $SQA -d $O/fast4_sqa -o run --output-format csv -- python3 $B --full-work
+run fast4_sqb --kernel-trace --pmc $SQB -d $O/fast4_sqb -o run --output-format csv -- python3 $B --full-work
+run fast4_fetch --kernel-trace --pmc FETCH_SIZE -d $O/fast4_fetch -o run --output-format csv -- python3 $B --full-work
+run fast4_write --kernel-trace --pmc WRITE_SIZE -d $O/fast4_write -o run --output-format csv -- python3 $B --full-work
+unset ORBX_FAST_IMPL
+# kernel durations at 64 frames per launch (BASELINE.json configs[2]; pools inside the Infinity Cache) and at 256
+B256="bench.py --only-timed --no-cpu-baseline --batch 256 --rotate 2 --steps 10 --warmup 2"
 for cfg in timed fullwork unfused; do
   case $cfg in
     timed) X="";;
@@ -45,7 +52,7 @@ for cfg in timed fullwork unfused; do
     unfused) X="--unfused";;
   esac
   run b64_${cfg}_stats --kernel-trace --stats -d $O/b64_${cfg}_stats -o run --output-format csv -- python3 $B64 $X
-  run b512_${cfg}_stats --kernel-trace --stats -d $O/b512_${cfg}_stats -o run --output-format csv -- python3 $B512 $X
+  run b256_${cfg}_stats --kernel-trace --stats -d $O/b256_${cfg}_stats -o run --output-format csv -- python3 $B256 $X
 done
 # BASELINE.json configs[4]: 1920x1080, 12 levels, 4000 features
 run hd_timed_stats --kernel-trace --stats -d $O/hd_timed_stats -o run --output-format csv -- python3 bench.py --workload 1080p --batch 32 --rotate 2 --steps 6 --warmup 1 --only-timed --no-cpu-baseline
@@ -54,7 +61,7 @@ run hd_fullwork_stats --kernel-trace --stats -d $O/hd_fullwork_stats -o run --ou
 # (8 x 1000-frame stream walked once), configs[4]
 python3 bench.py > $O/bench_default.json 2>> $O/log.txt || echo "FAILED bench_default" >> $O/log.txt
 python3 bench.py --batch 64 --rotate 4 --no-cpu-baseline > $O/bench_batch64.json 2>> $O/log.txt || echo "FAILED bench_batch64" >> $O/log.txt
-python3 bench.py --stream-frames 1000 --no-cpu-baseline > $O/bench_stream_8000.json 2>> $O/log.txt || echo "FAILED bench_stream" >> $O/log.txt
+ORBX_FAST_IMPL=4 python3 bench.py --no-cpu-baseline --strong-frames 0 > $O/bench_fast4.json 2>> $O/log.txt || echo "FAILED bench_fast4" >> $O/log.txt
 python3 bench.py --workload 1080p --batch 32 --rotate 2 --steps 10 --no-cpu-baseline > $O/bench_1080p.json 2>> $O/log.txt || echo "FAILED bench_1080p" >> $O/log.txt
 echo "bench lines done"
 # FETCH_SIZE / WRITE_SIZE calibration on known byte counts, per access width (tools/bw_probe.hip)
@@ -66,5 +73,5 @@ if [ -x tools/bw_probe.bin ]; then
     run calib_write_$mb --kernel-trace --pmc WRITE_SIZE -d $O/calib_write_$mb -o run --output-format csv -- ./tools/bw_probe.bin $mb
   done
 fi
-python3 tools/pmc_to_json.py $O profiles/r02 > $O/summary.txt 2>&1 || true
+python3 tools/pmc_to_json.py $O profiles/r03 1024 > $O/summary.txt 2>&1 || true
 tail -5 $O/summary.txt

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 runs of tools/pmc_collect.sh into profiles/r02/:
+"""Condense the rocprofv3 runs of tools/pmc_collect.sh into profiles/r03/:
   *_kernel_stats.csv   per-kernel duration statistics (from the kernel traces)
   pmc_counters.json    per-kernel counters per STEP + the FETCH_SIZE / WRITE_SIZE calibration, stamped
                        with the hash of the kernel sources (bench.py uses it only for the same sources)
@@ -51,12 +51,12 @@ def main():
     os.makedirs(dst, exist_ok=True)
     import bench
 
-    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
     res = {"source_sha": bench.kernel_source_sha(), "batch": batch,
            "workload": "bench.py default: KITTI 1241x376, 8 levels, %d frames per launch" % batch,
            "kernels": {}, "configs": {}}
-    for cfg in ("timed", "fullwork", "unfused", "b64_timed", "b64_fullwork", "b64_unfused", "b512_timed", "b512_fullwork",
-                "b512_unfused", "hd_timed", "hd_fullwork"):
+    for cfg in ("timed", "fullwork", "unfused", "fast4", "b64_timed", "b64_fullwork", "b64_unfused", "b256_timed", "b256_fullwork",
+                "b256_unfused", "hd_timed", "hd_fullwork"):
         st = trace_stats(os.path.join(src, cfg + "_stats"))
         if not st:
             continue
@@ -80,18 +80,27 @@ def main():
                               "write_kb": {k: v.get("WRITE_SIZE") for k, v in w.items()}}
     res["calibration"] = calib
     # what bench.py reads: per kernel VALU instructions and corrected HBM traffic per launch
+    def full_name(cfg, prefix):  # "k_fast3" -> "k_fast3<1>" as rocprofv3 prints the instantiation
+        names = [k for k in res["configs"].get(cfg, {}).get("us_per_step", {}) if k == prefix or k.startswith(prefix + "<")]
+        return max(names, key=lambda k: res["configs"][cfg]["us_per_step"][k]) if names else prefix
+
     def pick(cfg, kern, key):
-        return res["configs"].get(cfg, {}).get("counters", {}).get(kern, {}).get(key)
+        return res["configs"].get(cfg, {}).get("counters", {}).get(full_name(cfg, kern), {}).get(key)
 
     table = {"k_pyrblur": ("timed", "k_pyrblur"), "k_pyrblur_every_row": ("fullwork", "k_pyrblur"),
-             "k_fast3": ("timed", "k_fast3<1>"),
-             "k_fast3_full_work": ("fullwork", "k_fast3<1>"), "k_level_select": ("timed", "k_level_select"),
-             "k_describe2": ("timed", "k_describe2<4, 4, 7>"), "k_pyramid2": ("unfused", "k_pyramid2"),
+             "k_fast3": ("timed", "k_fast3"), "k_fast3_full_work": ("fullwork", "k_fast3"),
+             "k_fast4_full_work": ("fast4", "k_fast4"), "k_level_select": ("timed", "k_level_select"),
+             "k_describe2": ("timed", "k_describe2"), "k_pyramid2": ("unfused", "k_pyramid2"),
              "k_blur3": ("unfused", "k_blur3")}
     for name, (cfg, kern) in table.items():
         valu, fe, wr = pick(cfg, kern, "SQ_INSTS_VALU"), pick(cfg, kern, "FETCH_SIZE"), pick(cfg, kern, "WRITE_SIZE")
         e = {"valu": valu, "fetch_kb": fe, "write_kb": wr, "config": cfg,
-             "us_per_step_rocprof": res["configs"].get(cfg, {}).get("us_per_step", {}).get(kern)}
+             "us_per_step_rocprof": res["configs"].get(cfg, {}).get("us_per_step", {}).get(full_name(cfg, kern))}
+        for extra in ("SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",
+                      "SQ_LDS_IDX_ACTIVE", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
+            v = pick(cfg, kern, extra)
+            if v is not None:
+                e[extra.lower()] = v
         # gfx950: FETCH_SIZE reports exactly half of the bytes of a coalesced streaming read, at 4, 8 and
         # 16 B per lane alike, Infinity-Cache hits included (calibration below; MI355X_MICROARCH.md §HBM);
         # WRITE_SIZE reads the written bytes exactly
@@ -99,7 +108,7 @@ def main():
             e["traffic_bytes"] = (2.0 * fe + wr) * 1024.0
         res["kernels"][name] = e
     json.dump(res, open(os.path.join(dst, "pmc_counters.json"), "w"), indent=1, sort_keys=True)
-    for name in ("bench_default", "bench_batch64", "bench_stream_8000", "bench_1080p", "bw_probe_97", "bw_probe_1600"):
+    for name in ("bench_default", "bench_batch64", "bench_fast4", "bench_1080p", "bw_probe_97", "bw_probe_1600"):
         for ext in (".json", ".txt"):
             f = os.path.join(src, name + ext)
             if os.path.exists(f) and os.path.getsize(f) > 0:
