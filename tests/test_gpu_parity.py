@@ -247,6 +247,23 @@ def test_gpu_flavour_param_sweep(pkg, kw):
         check_whole(c.detect_and_compute(img), O.detect_and_compute_gpu(img, O.gpu_params(**base)))
 
 
+@pytest.mark.parametrize("nms_window", [0, 3, 5, 7])
+def test_threshold_zero_on_flat_and_saturated_content(pkg, nms_window):
+    """Threshold 0: a flat neighbourhood passes the pre-test and the arc test with score 0, and a score of 0 is no
+    keypoint (src/orb_cpu.cpp:110 skips scores <= 0 before it looks at the NMS radius) -- the case a fuzz campaign
+    of round 3 caught in the streaming FAST kernel (it kept such corners).  Flat stripes, saturated blocks with one
+    grey level of noise, and enough candidates per tile row to overflow the candidate queue."""
+    rng = np.random.default_rng(5)
+    img = np.zeros((134, 267), np.uint8)
+    img[:40] = 77  # flat
+    img[40:90] = np.where(rng.random((50, 267)) > 0.5, 255, 0)
+    img[90:] = (np.arange(267)[None, :] // 16 % 2 * 255 + rng.integers(0, 2, (44, 267))).clip(0, 255)
+    kw = dict(nfeatures=400, nlevels=5, scale_factor=1.5, threshold=0, n=9, nms_window=nms_window, blur_levels=1, blur_kind=1)
+    p = pkg.default_params("gpu", max_width=267, max_height=134, **kw)
+    with pkg.Context(p) as c:
+        check_whole(c.detect_and_compute(img), O.detect_and_compute_gpu(img, O.gpu_params(**kw)))
+
+
 def test_batch_matches_single_and_device_path(pkg, kitti0, kitti1):
     """Batched device-resident path == per-frame host path == oracle; ragged frame content."""
     import torch

@@ -73,6 +73,14 @@ def main():
         B = 40 if big else int(rng.choice([1, 2, 5, 9]))
         p = pkg.default_params("gpu", max_width=w, max_height=h, max_batch=B, select_mode=mode, **kw)
         imgs = np.stack([image(rng, h, w) for _ in range(B)])
+        # which FAST kernel the whole path runs (read when the context is created): the LDS tile kernel or the
+        # register-streaming one, every NMS radius / arc length / threshold through both
+        os.environ["ORBX_FAST_IMPL"] = "4" if rng.random() < 0.6 else "3"
+        # replay of one configuration of a campaign: FUZZ_ONLY=<it> [FUZZ_IMPL=3|4] (the configurations before it run
+        # too, unchecked, so that the generator is consumed exactly as in the campaign)
+        only = os.environ.get("FUZZ_ONLY")
+        if only is not None and int(only) == it and os.environ.get("FUZZ_IMPL"):
+            os.environ["ORBX_FAST_IMPL"] = os.environ["FUZZ_IMPL"]
         try:
             with pkg.Context(p) as c:
                 cap = max(c.plan(w, h)["out_capacity"], 1)
@@ -87,10 +95,12 @@ def main():
                     torch.cuda.synchronize()
                     c.batch_host(imgs[:1])  # (sets the plan: the lanes engage for an unchanged frame size)
                     c.set_pipelined_batches(True)
-                    c.batch_device(d_rev.data_ptr(), B, w, h)
-                    c.batch_device(d_img.data_ptr(), B, w, h)
-                    c.batch_device(d_rev.data_ptr(), B, w, h)
-                    c.batch_device(d_img.data_ptr(), B, w, h)
+                    own = torch.cuda.Stream() if rng.random() < 0.5 else None  # some batches on a caller's stream
+                    for dd in (d_rev, d_img, d_rev, d_img):
+                        st_ = own.cuda_stream if own is not None and rng.random() < 0.5 else None
+                        c.batch_device(dd.data_ptr(), B, w, h, stream=st_)
+                    if own is not None and rng.random() < 0.5:  # make sure the LAST batch is the real one on either path
+                        c.batch_device(d_img.data_ptr(), B, w, h, stream=own.cuda_stream)
                     r = c.batch_fetch(0, B, cap)
                     c.set_pipelined_batches(False)
                 else:
@@ -103,6 +113,9 @@ def main():
             if e.status == pkg.orbx.ERR_UNSUPPORTED:
                 continue
             raise
+        if only is not None and int(only) != it:
+            it += 1
+            continue
         for i in range(B):
             if mode == 0:
                 ref = O.detect_and_compute_gpu(imgs[i], O.gpu_params(**kw))
@@ -111,12 +124,14 @@ def main():
             n = int(r["counts"][i])
             got = dict(count=n, kps=r["kps"][i, :n], kps_level=r["kps_level"][i, :n], levels=r["levels"][i, :n],
                        angles=r["angles"][i, :n], responses=r["responses"][i, :n], desc=r["desc"][i, :n])
-            check(got, ref, (it, i, w, h, kw, mode))
+            check(got, ref, (it, i, w, h, kw, mode, os.environ["ORBX_FAST_IMPL"]))
             if i == 0:
                 check(single, ref, (it, "single", w, h, kw, mode))
             frames += 1
             kps += n
         it += 1
+        if only is not None:
+            break
     print("fuzz ok: %d configurations, %d frames, %d keypoints in %.0f s (seed %d)" % (it, frames, kps, time.time() - t0, seed))
 
 

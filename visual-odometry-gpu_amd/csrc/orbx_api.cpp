@@ -421,6 +421,30 @@ void build_blur_tiles(const OrbxPlan& plan, std::vector<OrbxTileDesc>* out) {
   }
 }
 
+// units of k_blur4 for ONE frame: per level ceil(pitch / 256) strips x waves of FOUR row bands each (f = rows per
+// band: a level's height spread over the fewest waves whose bands stay within ORBX_BLUR4_RH rows)
+void build_blur4_tiles(const OrbxPlan& plan, std::vector<OrbxTileDesc>* out) {
+  out->clear();
+  for (int l = 0; l < plan.nlevels; l++) {
+    const OrbxLevel& L = plan.L[l];
+    const int ntx = (L.pitch + ORBX_BLUR4_TW - 1) / ORBX_BLUR4_TW;  // the padding bytes are (re)written as zeros
+    const int nwv = (L.h + 4 * ORBX_BLUR4_RH - 1) / (4 * ORBX_BLUR4_RH), rows = (L.h + 4 * nwv - 1) / (4 * nwv);
+    for (int wv = 0; wv < nwv; wv++)
+      for (int tx = 0; tx < ntx; tx++) {
+        OrbxTileDesc d{};
+        d.l = l;
+        d.tx = tx;
+        d.ty = wv * 4 * rows;
+        d.f = rows;
+        d.w = L.w;
+        d.h = L.h;
+        d.pitch = L.pitch;
+        d.img_off = (uint64_t)L.img_off;
+        if (d.ty < L.h) out->push_back(d);
+      }
+  }
+}
+
 // strips of the fused pyramid + blur kernel for ONE frame: 248-px strips (the halo dwords are
 // computed by lanes 0 / 63) x balanced row bands, with the level's resize-table fields.
 // part 0: every row.  Top-rows-first pipeline (enqueue_batch): part 1 = the rows the FAST tiles of the
@@ -664,6 +688,8 @@ int validate_params(const orbx_params& p, std::string* why) {
   return ORBX_OK;
 }
 
+void blur_tiles_for_impl(const OrbxPlan& plan, std::vector<OrbxTileDesc>* out);
+
 // the working pools of lane k become the context's current ones
 void use_lane(orbx_ctx* c, int k) {
   const orbx_ctx::LanePool& L = c->lane_pool[k];
@@ -719,7 +745,7 @@ int set_plan(orbx_ctx* c, int w, int h) {
   if ((st = make_bandmap(plan, c->p.nms_window / 2, &c->bm_fast, &why, c->fast_impl == 4)) != ORBX_OK) return fail(c, st, why);
   {
     std::vector<OrbxTileDesc> t;
-    build_blur_tiles(plan, &t);
+    blur_tiles_for_impl(plan, &t);
     if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "blur tile table exceeds pool");
     HIPCHK(c, hipMemcpy(c->d_tiles_blur, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
     c->blur_tiles_count = (int)t.size();
@@ -818,16 +844,29 @@ hipError_t launch_fast_whole(orbx_ctx* c, hipStream_t s, int n, OrbxFastParams f
   return launch_fast_tiles(c, s, 0, c->fast_tiles_count, n, fp, stat);
 }
 
-// separable kind -> register-streaming kernel; /273 kind -> LDS tile kernel.
-// ORBX_BLUR_IMPL=1 forces the first-generation kernel (A/B timing).
-hipError_t launch_blur_auto(hipStream_t s, const OrbxPlan& P, const OrbxTileMap& tm1, const OrbxTileDesc* tiles2,
-                            int ntiles2, int n, const uint8_t* src, uint8_t* dst, int first_level, int kind) {
+// separable kind -> register-streaming kernel (16 pixels per lane: k_blur4); /273 kind -> LDS tile kernel.
+// ORBX_BLUR_IMPL=2: the 4-pixels-per-lane streaming kernel (k_blur3), 1: the first-generation LDS tile kernel (A/B
+// timing; the strip table is built for the kernel that will read it: blur_tiles_for_impl).
+int blur_impl_env() {
   static const int impl = [] {
     const char* e = getenv("ORBX_BLUR_IMPL");
-    return e ? atoi(e) : 2;
+    return e ? atoi(e) : 3;
   }();
-  if (kind == ORBX_BLUR_SEP16 && impl != 1)
+  return impl;
+}
+void blur_tiles_for_impl(const OrbxPlan& plan, std::vector<OrbxTileDesc>* out) {
+  if (blur_impl_env() == 2)
+    build_blur_tiles(plan, out);
+  else
+    build_blur4_tiles(plan, out);
+}
+hipError_t launch_blur_auto(hipStream_t s, const OrbxPlan& P, const OrbxTileMap& tm1, const OrbxTileDesc* tiles2,
+                            int ntiles2, int n, const uint8_t* src, uint8_t* dst, int first_level, int kind) {
+  const int impl = blur_impl_env();
+  if (kind == ORBX_BLUR_SEP16 && impl == 2)
     return orbx_launch_blur3(s, tiles2, ntiles2, P.frame_bytes, n, src, dst, first_level);
+  if (kind == ORBX_BLUR_SEP16 && impl != 1)
+    return orbx_launch_blur4(s, tiles2, ntiles2, P.frame_bytes, n, src, dst, first_level);
   return orbx_launch_blur(s, P, tm1, n, src, dst, first_level, kind);
 }
 const uint8_t* final_pyr(const orbx_ctx* c) { return blur_enabled(c) ? c->d_pyr_blur : c->d_pyr; }
@@ -1302,7 +1341,7 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
     c->tiles_fast_capacity = (size_t)bmm.band_begin[bmm.nbands];
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_fast, std::max<size_t>(c->tiles_fast_capacity, 1) * sizeof(OrbxTileDesc)));
     std::vector<OrbxTileDesc> t1, t2;
-    build_blur_tiles(M, &t1);
+    blur_tiles_for_impl(M, &t1);
     build_frame_tiles(M, ORBX_PYR2_TW, ORBX_PYR2_TH, true, &t2);
     std::vector<OrbxTileDesc> t3, t4;
     build_pyrblur_tiles(M, ORBX_PYRBLUR_RH, &t3);
@@ -1978,7 +2017,7 @@ static int blur_stage(orbx_ctx* c, const uint8_t* image, int width, int height, 
   OrbxTileMap tm;
   make_tilemap(P, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &tm);
   std::vector<OrbxTileDesc> t;
-  build_blur_tiles(P, &t);
+  blur_tiles_for_impl(P, &t);
   if ((st = ensure(c, c->s_tiles, t.size() * sizeof(OrbxTileDesc))) != ORBX_OK) return st;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->s_tiles.p, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));

@@ -202,6 +202,182 @@ __global__ __launch_bounds__(256) void k_blur3(const OrbxTileDesc* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same blur with SIXTEEN pixels per lane (k_blur4; the stand-alone blur of the stage operator and of the
+// blur_levels = none / upper modes).  tools/bw_probe.hip: a wave row of 64 x 4 bytes reads at 3.8 TB/s and copies at
+// 4.7, 64 x 16 bytes at 6.2 / 5.1 -- and k_blur3 moved its traffic at exactly the 4-byte copy rate.  A 1024-pixel
+// wave row would waste most lanes on this path's level widths (1241, 1034, 862, ... : 61 % of the lanes at level 0),
+// so the wave is FOUR row bands of 16 lanes: lane = 16 * band + column, a lane owns 16 pixels (one dwordx4 per row
+// for the load and for the store), a wave 256 pixels x 4 bands of the same strip.  The neighbours of the horizontal
+// pass are the lane's own dwords except at its two ends: DPP row_shr / row_shl (rows of 16 lanes = the bands) -- 2
+// DPP + 18 v_perm per 16 pixels where four 4-pixel lanes need 8 + 24 --, the two dwords beyond a band's strip
+// arrive with one extra 8-lane load per row.  Bands are tall (a level's height / 4, at most ORBX_BLUR4_RH rows), so
+// the 4 warm-up rows of the vertical pass are 4 % of a KITTI level instead of 6.
+struct Blur4Lane {
+  __amdgpu_buffer_rsrc_t rin, rout;
+  uint32_t xoff, xhalo;  // byte offset of the lane's 16 pixels / of its halo dword (or out of range)
+  int y0, yend, h, pitch;
+  uint32_t selL[4], selC[4], selR[4], vmask[4];  // column REFLECT_101 per dword (PATCH waves only)
+};
+
+template <bool PATCH>
+__device__ __forceinline__ void blur4_rows(const Blur4Lane& S, int nr) {
+  const uint32_t k4 = pk_opaque(0x00040004u), k6 = pk_opaque(0x00060006u);
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  uint32_t he[5][4], ho[5][4];
+  u32x4 raw[5];
+  uint32_t rawh[5];
+  // input row r of a band is level row reflect(y0 - 2 + r) (per lane: the bands of a wave start at different rows)
+  auto load = [&](int r, u32x4& c, uint32_t& hh) {
+    int y = S.y0 - 2 + r;
+    y = max(y, -y);
+    y = min(y, 2 * S.h - 2 - y);
+    const uint32_t ro = (uint32_t)(y * S.pitch);
+    c = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(S.rin, ro + S.xoff, 0, 0));
+    hh = __builtin_amdgcn_raw_buffer_load_b32(S.rin, ro + S.xhalo, 0, 0);
+  };
+  auto hpass = [&](int k) {
+    const u32x4 c = raw[k];
+    const uint32_t C0[4] = {c.x, c.y, c.z, c.w};
+    // rows of 16 lanes = bands: the lane without a source lane (column 0 / 15) keeps `old` = its halo dword
+    const uint32_t Ld = __builtin_amdgcn_update_dpp(rawh[k], C0[3], 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+    const uint32_t Rd = __builtin_amdgcn_update_dpp(rawh[k], C0[0], 0x101 /*row_shl:1*/, 0xf, 0xf, false);
+    if (PATCH) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t Lraw = j == 0 ? Ld : C0[j - 1], Rraw = j == 3 ? Rd : C0[j + 1];
+        const uint32_t Lw = __builtin_amdgcn_perm(C0[j], Lraw, S.selL[j]);
+        const uint32_t C = __builtin_amdgcn_perm(C0[j], Lw, S.selC[j]);
+        const uint32_t Rw = __builtin_amdgcn_perm(C0[j], Rraw, S.selR[j]);
+        const uint32_t A = __builtin_amdgcn_perm(C, Lw, 0x0c040c02u), B = __builtin_amdgcn_perm(C, Lw, 0x0c050c03u);
+        const uint32_t Cc = __builtin_amdgcn_perm(C, C, 0x0c020c00u), D = __builtin_amdgcn_perm(C, C, 0x0c030c01u);
+        const uint32_t E = __builtin_amdgcn_perm(Rw, C, 0x0c040c02u), F = __builtin_amdgcn_perm(Rw, C, 0x0c050c03u);
+        he[k][j] = pk_mad_r(pk_add(B, D), k4, pk_mad_r(Cc, k6, pk_add(A, E)));
+        ho[k][j] = pk_mad_r(pk_add(Cc, E), k4, pk_mad_r(D, k6, pk_add(B, F)));
+      }
+    } else {
+      uint32_t A = __builtin_amdgcn_perm(C0[0], Ld, 0x0c040c02u), B = __builtin_amdgcn_perm(C0[0], Ld, 0x0c050c03u);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t C = C0[j], Rw = j == 3 ? Rd : C0[j + 1];
+        const uint32_t Cc = __builtin_amdgcn_perm(C, C, 0x0c020c00u), D = __builtin_amdgcn_perm(C, C, 0x0c030c01u);
+        const uint32_t E = __builtin_amdgcn_perm(Rw, C, 0x0c040c02u), F = __builtin_amdgcn_perm(Rw, C, 0x0c050c03u);
+        he[k][j] = pk_mad_r(pk_add(B, D), k4, pk_mad_r(Cc, k6, pk_add(A, E)));
+        ho[k][j] = pk_mad_r(pk_add(Cc, E), k4, pk_mad_r(D, k6, pk_add(B, F)));
+        A = E;  // (x+2, x+4) and (x+3, x+5) of this dword are (x-2, x) and (x-1, x+1) of the next one
+        B = F;
+      }
+    }
+  };
+  // vertical pass over ring slots a..e (a = oldest) -> output row y of every band (y is per lane)
+  auto vpass = [&](int a, int b, int c, int d, int e, int rel) {
+    const int y = S.y0 + rel;
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t te = pk_rne8_hi(pk_mad_r(pk_add(he[b][j], he[d][j]), k4, pk_mad_r(he[c][j], k6, pk_add(he[a][j], he[e][j]))));
+      const uint32_t to = pk_rne8_hi(pk_mad_r(pk_add(ho[b][j], ho[d][j]), k4, pk_mad_r(ho[c][j], k6, pk_add(ho[a][j], ho[e][j]))));
+      o[j] = __builtin_amdgcn_perm(to, te, 0x07030501u);
+      if (PATCH) o[j] &= S.vmask[j];
+    }
+    const uint32_t vo = y < S.yend ? (uint32_t)(y * S.pitch) + S.xoff : 0x7fffff00u;  // (out of range: dropped)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned,
+                                                              u32x4{o[0], o[1], o[2], o[3]}),
+                                           S.rout, vo, 0, 0);
+  };
+#pragma unroll
+  for (int k = 0; k < 5; k++) load(k, raw[k], rawh[k]);
+  // first group: four warm-up rows, the fifth completes output row y0; each row's registers are refilled with the
+  // row five further down as soon as its horizontal pass has consumed them
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    hpass(k);
+    load(min(5 + k, nr + 1), raw[k], rawh[k]);
+  }
+  vpass(0, 1, 2, 3, 4, 0);
+  for (int rb = 5; rb < nr; rb += 5) {  // wave-uniform
+    const int rel = rb - 4;
+    hpass(0);
+    load(min(rb + 5, nr + 1), raw[0], rawh[0]);
+    vpass(1, 2, 3, 4, 0, rel);
+    hpass(1);
+    load(min(rb + 6, nr + 1), raw[1], rawh[1]);
+    vpass(2, 3, 4, 0, 1, rel + 1);
+    hpass(2);
+    load(min(rb + 7, nr + 1), raw[2], rawh[2]);
+    vpass(3, 4, 0, 1, 2, rel + 2);
+    hpass(3);
+    load(min(rb + 8, nr + 1), raw[3], rawh[3]);
+    vpass(4, 0, 1, 2, 3, rel + 3);
+    hpass(4);
+    load(min(rb + 9, nr + 1), raw[4], rawh[4]);
+    vpass(0, 1, 2, 3, 4, rel + 4);
+  }
+}
+
+// grid = (table entries of ONE frame / 4, frames); wave w of a workgroup owns entry 4 * blockIdx.x + w: level `l`,
+// strip `tx` (256 px), four bands of `f` rows starting at row ty.
+__global__ __launch_bounds__(256) void k_blur4(const OrbxTileDesc* __restrict__ tiles, int n_tiles, int frame_bytes,
+                                               const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                               int first_level) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ti = blockIdx.x * 4 + wave;
+  if (ti >= n_tiles) return;  // whole wave
+  const OrbxTileDesc d = tiles[ti];
+  const int w = d.w, h = d.h, pitch = d.pitch, rows = d.f;
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, band = lane >> 4, col = lane & 15;
+  const int x = d.tx * ORBX_BLUR4_TW + 16 * col;
+  Blur4Lane S;
+  S.h = h;
+  S.pitch = pitch;
+  S.y0 = d.ty + band * rows;
+  S.yend = min(S.y0 + rows, h);
+  const bool live = x < pitch && S.y0 < h;  // (a band past the level's last row, a lane past its pitch: nothing to do)
+  if (!live) S.y0 = 0, S.yend = 0;
+  const size_t level_off = (size_t)f * frame_bytes + d.img_off;
+  S.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src) + level_off, 0, pitch * h, 0x00020000);
+  S.rout = __builtin_amdgcn_make_buffer_rsrc(dst + level_off, 0, pitch * h, 0x00020000);
+  constexpr uint32_t OUT = 0x7fffff00u;  // with any row offset added still far beyond a level: loads give 0, stores are dropped
+  S.xoff = live ? (uint32_t)x : OUT;
+  const int xh = col == 0 ? x - 4 : x + 16;
+  S.xhalo = (live && (col == 0 || col == 15) && xh >= 0 && xh < pitch) ? (uint32_t)xh : OUT;
+
+  if (d.l < first_level) {  // pass-through copy
+    for (int r = 0; r < rows; r++) {  // wave-uniform trip count; lanes past their band address out of range
+      const int y = S.y0 + r;
+      const uint32_t o = y < S.yend ? (uint32_t)(y * pitch) + S.xoff : OUT;
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(S.rin, o, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v, S.rout, o, 0, 0);
+    }
+    return;
+  }
+  const int e4 = (w - 1) & ~3, rbyte = (w - 1) & 3;
+  const int x_lo = d.tx * ORBX_BLUR4_TW, x_hi = x_lo + ORBX_BLUR4_TW - 4;
+  // only the waves that hold x = 0, the image's last pixels or padding need the column patches (wave-uniform)
+  const bool patch = x_lo == 0 || x_hi + 4 >= e4;
+  const int nr = rows + 4;  // input rows of the tallest band
+  if (patch) {
+    const uint32_t selC_e = rbyte == 3 ? 0x07060504u : rbyte == 2 ? 0x05060504u : rbyte == 1 ? 0x03040504u : 0x07020304u;
+    const uint32_t selR_e = rbyte == 3 ? 0x0c0c0506u : rbyte == 2 ? 0x0c0c0c04u : 0x0c0c0c0cu;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int xj = x + 4 * j;
+      const bool edge = xj == e4;
+      // (neighbour dwords are taken RAW here, so the dword left of an edge dword that holds one pixel builds x = w
+      // -- the reflection of its own last byte -- itself, whichever lane or dword the edge is in)
+      S.selL[j] = xj == 0 ? 0x05060c0cu : 0x03020100u;
+      S.selC[j] = edge ? selC_e : 0x07060504u;
+      S.selR[j] = edge ? selR_e : (xj + 4 == e4 && rbyte == 0) ? 0x0c0c0700u : 0x03020100u;
+      const int nvalid = w - xj;
+      S.vmask[j] = nvalid >= 4 ? 0xffffffffu : nvalid <= 0 ? 0u : ((1u << (8 * nvalid)) - 1u);
+    }
+    blur4_rows<true>(S, nr);
+  } else {
+    blur4_rows<false>(S, nr);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Pyramid + blur in ONE pass (whole path, blur on every level): the wave produces each row of its
 // strip of level l straight from the input frame -- level 0: the frame's own pixels; level >= 1:
 // OpenCV's 8UC1 fixed-point bilinear resize of level 0 (src/orb.cpp:111-120; the arithmetic of
@@ -517,6 +693,15 @@ hipError_t orbx_launch_blur3(hipStream_t s, const OrbxTileDesc* d_tiles, int n_t
   // four waves per workgroup (measured: 1 -> 53 us, 2 -> 48 us, 4 -> 43 us, 8 / 16 -> 46 us per 64-frame batch)
   dim3 grid(((n_tiles + 3) / 4) | 1, n_frames);  // odd: see orbx_launch_pyrblur
   hipLaunchKernelGGL(k_blur3, grid, dim3(256), 0, s, d_tiles, n_tiles, frame_bytes, d_src, d_dst, first_level);
+  return hipGetLastError();
+}
+
+// the same with 16 pixels per lane; d_tiles: orbx_api.cpp: build_blur4_tiles (level, strip, first row, rows per band)
+hipError_t orbx_launch_blur4(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int n_frames,
+                             const uint8_t* d_src, uint8_t* d_dst, int first_level) {
+  if (n_tiles <= 0 || n_frames <= 0) return hipSuccess;
+  dim3 grid(((n_tiles + 3) / 4) | 1, n_frames);  // odd: see orbx_launch_pyrblur
+  hipLaunchKernelGGL(k_blur4, grid, dim3(256), 0, s, d_tiles, n_tiles, frame_bytes, d_src, d_dst, first_level);
   return hipGetLastError();
 }
 

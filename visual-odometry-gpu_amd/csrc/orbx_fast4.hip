@@ -276,11 +276,13 @@ __global__ __launch_bounds__(64) void k_fast4(const OrbxTileDesc* __restrict__ t
         if (kk < narc_any) a &= rot(a, 2 * (narc_any - kk));
       }
       const bool corner = a != 0u;
-      if (active && corner) {
-        if (R > 0) {
-          uint32_t score = 0;
+      uint32_t score = 0;
 #pragma unroll
-          for (int i = 0; i < 16; i++) score = __builtin_amdgcn_sad_u16((uint32_t)Ip, (uint32_t)v[i], score);
+      for (int i = 0; i < 16; i++) score = __builtin_amdgcn_sad_u16((uint32_t)Ip, (uint32_t)v[i], score);
+      // (threshold 0: a flat neighbourhood passes the arc test with score 0, and a score of 0 is no keypoint:
+      // src/orb_cpu.cpp:110 skips scores <= 0 before it looks at the NMS radius)
+      if (active && corner && score > 0u) {
+        if (R > 0) {
           int s = sm0 + k;
           s = s >= C::NS ? s - C::NS : s;
           // (the score rows are never cleared: an entry carries the low bits of its centre row's index, and a row's

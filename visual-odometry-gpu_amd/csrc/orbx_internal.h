@@ -137,6 +137,9 @@ constexpr int orbx_fast4_strips(int w, int nms_radius) {
 // 256-byte segment per row) over a band of at most ORBX_BLUR3_RH rows
 #define ORBX_BLUR3_TW 256
 #define ORBX_BLUR3_RH 64
+// k_blur4: 16 pixels per lane, a wave = a 256-px strip x 4 row bands of at most ORBX_BLUR4_RH rows
+#define ORBX_BLUR4_TW 256
+#define ORBX_BLUR4_RH 96
 // fused pyramid + blur: the halo dwords are computed, not loaded, so lanes 0 / 63 are halo-only
 #define ORBX_PYRBLUR_TW 248
 // rows per band of the fused kernel: the y taps of a band's input rows (rows + 6) sit one per lane
@@ -178,6 +181,8 @@ hipError_t orbx_launch_blur(hipStream_t s, const OrbxPlan& plan, const OrbxTileM
                             const uint8_t* d_src, uint8_t* d_dst, int first_level, int kind);
 // d_tiles: strip table of ONE frame (level, strip, first row, rows)
 hipError_t orbx_launch_blur3(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int n_frames,
+                             const uint8_t* d_src, uint8_t* d_dst, int first_level);
+hipError_t orbx_launch_blur4(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int n_frames,
                              const uint8_t* d_src, uint8_t* d_dst, int first_level);
 // d_tiles: strip table of ONE frame with the pyramid fields (u0 / u1 / u2 = xtab_off / ytab_off / win8)
 hipError_t orbx_launch_pyrblur(hipStream_t s, const OrbxTileDesc* d_tiles, int n_tiles, int frame_bytes, int w0, int h0,
