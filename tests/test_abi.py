@@ -108,7 +108,7 @@ def test_no_result_altering_environment_switch_in_the_shipping_library():
         "ORBX_FAST_EARLY",     # 0: every FAST tile does the full work (tests/test_gpu_parity.py: bit-equal)
         "ORBX_GRAPH",          # 0: plain launches instead of the captured hipGraph
         "ORBX_SELECT_SPREAD",  # fused vs three-kernel selection
-        "ORBX_BLUR_IMPL",      # first- vs second-generation separable blur kernel
+        "ORBX_BLUR_IMPL",      # which separable blur kernel: LDS tiles / 4 pixels per lane (default) / 16 pixels per lane
         "ORBX_FUSE",           # 0: pyramid and blur as two kernels instead of one
         "ORBX_PYR_GROUP",      # frames per dispatch group of the fused kernel (tests/test_batch64_parity.py)
         "ORBX_FAST_CHUNK",     # tiles per FAST workgroup (tests/test_batch64_parity.py)

@@ -366,6 +366,38 @@ def test_blur_width_sweep(ctx, w):
         assert np.array_equal(ctx.blur5_sep(img), O.blur5_sep(img)), (w, h)
 
 
+@pytest.fixture(scope="module")
+def ctx_blur16(pkg):
+    """a context whose stand-alone blur is k_blur4 (16 pixels per lane, four row bands per wave): ORBX_BLUR_IMPL=3,
+    read when the context is created"""
+    import os
+
+    old = os.environ.get("ORBX_BLUR_IMPL")
+    os.environ["ORBX_BLUR_IMPL"] = "3"
+    try:
+        c = pkg.Context(pkg.default_params("gpu", max_width=1920, max_height=1080, max_batch=4))
+    finally:
+        if old is None:
+            del os.environ["ORBX_BLUR_IMPL"]
+        else:
+            os.environ["ORBX_BLUR_IMPL"] = old
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("w", [8, 9, 15, 16, 17, 63, 64, 65, 240, 243, 244, 245, 248, 249, 252, 253, 254, 255, 256, 257, 258, 259, 260,
+                               261, 262, 272, 497, 508, 509, 511, 512, 513, 514, 516, 767, 768, 769, 770, 772, 1241, 1920])
+def test_blur16_width_sweep(ctx_blur16, w):
+    """k_blur4: the dword holding the last pixel on every dword of a lane and in the halo of a band's last lane, every
+    byte position; heights around the four-band split (a last band that is short, or missing) and the 5-row groups;
+    levels taller than one wave's four bands."""
+    for h in (8, 9, 17, 21, 64, 66, 71, 129, 385, 391):
+        if w > 1000 and h not in (8, 129, 391):
+            continue
+        img = synth(w * 131 + h, h, w, "noise")
+        assert np.array_equal(ctx_blur16.blur5_sep(img), O.blur5_sep(img)), (w, h)
+
+
 @pytest.mark.parametrize("shape", [(64, 64), (65, 65), (127, 129), (128, 128), (129, 127), (70, 200), (200, 70),
                                    (191, 255), (193, 257)])
 def test_whole_path_tile_boundaries(pkg, shape):

@@ -190,6 +190,7 @@ struct orbx_ctx {
 
   int timing = 0;  // 0 off, 1 all stages, 2 blur + fast only
   int fast_early = 1;
+  int blur_impl = 2;  // ORBX_BLUR_IMPL, read at creation (launch_blur_auto)
   int fast_impl = 3;  // 3: LDS tile kernel (orbx_fast.hip), 4: streaming kernel (orbx_fast4.hip); ORBX_FAST_IMPL, read at creation
   int fuse = 1;  // pyramid + blur in one kernel when blur runs on every level (orbx_set_fused_pyramid_blur)
   // Top-rows-first pipeline (enqueue_batch): 0 never, 1 whenever eligible, 2 adaptive -- the second pass
@@ -688,7 +689,7 @@ int validate_params(const orbx_params& p, std::string* why) {
   return ORBX_OK;
 }
 
-void blur_tiles_for_impl(const OrbxPlan& plan, std::vector<OrbxTileDesc>* out);
+void blur_tiles_for_impl(int impl, const OrbxPlan& plan, std::vector<OrbxTileDesc>* out);
 
 // the working pools of lane k become the context's current ones
 void use_lane(orbx_ctx* c, int k) {
@@ -745,7 +746,7 @@ int set_plan(orbx_ctx* c, int w, int h) {
   if ((st = make_bandmap(plan, c->p.nms_window / 2, &c->bm_fast, &why, c->fast_impl == 4)) != ORBX_OK) return fail(c, st, why);
   {
     std::vector<OrbxTileDesc> t;
-    blur_tiles_for_impl(plan, &t);
+    blur_tiles_for_impl(c->blur_impl, plan, &t);
     if (t.size() > c->tiles_frame_capacity) return fail(c, ORBX_ERR_UNSUPPORTED, "blur tile table exceeds pool");
     HIPCHK(c, hipMemcpy(c->d_tiles_blur, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
     c->blur_tiles_count = (int)t.size();
@@ -844,29 +845,27 @@ hipError_t launch_fast_whole(orbx_ctx* c, hipStream_t s, int n, OrbxFastParams f
   return launch_fast_tiles(c, s, 0, c->fast_tiles_count, n, fp, stat);
 }
 
-// separable kind -> register-streaming kernel (16 pixels per lane: k_blur4); /273 kind -> LDS tile kernel.
-// ORBX_BLUR_IMPL=2: the 4-pixels-per-lane streaming kernel (k_blur3), 1: the first-generation LDS tile kernel (A/B
-// timing; the strip table is built for the kernel that will read it: blur_tiles_for_impl).
+// separable kind -> register-streaming kernel; /273 kind -> LDS tile kernel.
+// ORBX_BLUR_IMPL (read when a context is created): 2 (default) k_blur3, 4 pixels per lane; 3: k_blur4, 16 pixels per
+// lane (measured 9 % slower: the blur's vertical pass dominates its instruction count, and 94 registers leave 5
+// waves per SIMD); 1: the first-generation LDS tile kernel.  The strip table is built for the kernel that reads it.
 int blur_impl_env() {
-  static const int impl = [] {
-    const char* e = getenv("ORBX_BLUR_IMPL");
-    return e ? atoi(e) : 3;
-  }();
-  return impl;
+  const char* e = getenv("ORBX_BLUR_IMPL");
+  const int v = e ? atoi(e) : 2;
+  return v >= 1 && v <= 3 ? v : 2;
 }
-void blur_tiles_for_impl(const OrbxPlan& plan, std::vector<OrbxTileDesc>* out) {
-  if (blur_impl_env() == 2)
-    build_blur_tiles(plan, out);
-  else
+void blur_tiles_for_impl(int impl, const OrbxPlan& plan, std::vector<OrbxTileDesc>* out) {
+  if (impl == 3)
     build_blur4_tiles(plan, out);
+  else
+    build_blur_tiles(plan, out);
 }
-hipError_t launch_blur_auto(hipStream_t s, const OrbxPlan& P, const OrbxTileMap& tm1, const OrbxTileDesc* tiles2,
+hipError_t launch_blur_auto(int impl, hipStream_t s, const OrbxPlan& P, const OrbxTileMap& tm1, const OrbxTileDesc* tiles2,
                             int ntiles2, int n, const uint8_t* src, uint8_t* dst, int first_level, int kind) {
-  const int impl = blur_impl_env();
-  if (kind == ORBX_BLUR_SEP16 && impl == 2)
-    return orbx_launch_blur3(s, tiles2, ntiles2, P.frame_bytes, n, src, dst, first_level);
-  if (kind == ORBX_BLUR_SEP16 && impl != 1)
+  if (kind == ORBX_BLUR_SEP16 && impl == 3)
     return orbx_launch_blur4(s, tiles2, ntiles2, P.frame_bytes, n, src, dst, first_level);
+  if (kind == ORBX_BLUR_SEP16 && impl != 1)
+    return orbx_launch_blur3(s, tiles2, ntiles2, P.frame_bytes, n, src, dst, first_level);
   return orbx_launch_blur(s, P, tm1, n, src, dst, first_level, kind);
 }
 const uint8_t* final_pyr(const orbx_ctx* c) { return blur_enabled(c) ? c->d_pyr_blur : c->d_pyr; }
@@ -960,7 +959,7 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
     HIPCHK(c, launch_pyramid_auto(c, s, n, d_frames, row_stride, frame_stride));
     HIPCHK(c, mark(1, true));
     if (blur_enabled(c))
-      HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->d_tiles_blur, c->blur_tiles_count, n, c->d_pyr,
+      HIPCHK(c, launch_blur_auto(c->blur_impl, s, P, c->tm_blur, c->d_tiles_blur, c->blur_tiles_count, n, c->d_pyr,
                                  c->d_pyr_blur, c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
   }
   if (!two_pass) {
@@ -1300,6 +1299,7 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
   c->device = dev;
 
   c->fast_impl = fast_impl_env();
+  c->blur_impl = blur_impl_env();
   st = build_plan(c->p, p->max_width, p->max_height, &c->plan_max, &why, c->fast_impl);
   if (st != ORBX_OK) {
     delete c;
@@ -1341,7 +1341,7 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
     c->tiles_fast_capacity = (size_t)bmm.band_begin[bmm.nbands];
     CREATE_CHK(hipMalloc((void**)&c->d_tiles_fast, std::max<size_t>(c->tiles_fast_capacity, 1) * sizeof(OrbxTileDesc)));
     std::vector<OrbxTileDesc> t1, t2;
-    blur_tiles_for_impl(M, &t1);
+    blur_tiles_for_impl(c->blur_impl, M, &t1);
     build_frame_tiles(M, ORBX_PYR2_TW, ORBX_PYR2_TH, true, &t2);
     std::vector<OrbxTileDesc> t3, t4;
     build_pyrblur_tiles(M, ORBX_PYRBLUR_RH, &t3);
@@ -1800,7 +1800,7 @@ int orbx_bench_stage(orbx_ctx* c, int n_frames, int stage, int reps, float* avg_
     switch (stage) {
       case ORBX_STAGE_BLUR:
         if (!blur_enabled(c)) return fail(c, ORBX_ERR_INVALID_ARG, "blur is disabled in this context");
-        HIPCHK(c, launch_blur_auto(s, P, c->tm_blur, c->d_tiles_blur, c->blur_tiles_count, n_frames, c->d_pyr,
+        HIPCHK(c, launch_blur_auto(c->blur_impl, s, P, c->tm_blur, c->d_tiles_blur, c->blur_tiles_count, n_frames, c->d_pyr,
                                    c->d_pyr_blur,
                                    c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
         break;
@@ -2017,11 +2017,11 @@ static int blur_stage(orbx_ctx* c, const uint8_t* image, int width, int height, 
   OrbxTileMap tm;
   make_tilemap(P, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &tm);
   std::vector<OrbxTileDesc> t;
-  blur_tiles_for_impl(P, &t);
+  blur_tiles_for_impl(c->blur_impl, P, &t);
   if ((st = ensure(c, c->s_tiles, t.size() * sizeof(OrbxTileDesc))) != ORBX_OK) return st;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->s_tiles.p, t.data(), t.size() * sizeof(OrbxTileDesc), hipMemcpyHostToDevice));
-  HIPCHK(c, launch_blur_auto(c->stream, P, tm, (const OrbxTileDesc*)c->s_tiles.p, (int)t.size(), 1,
+  HIPCHK(c, launch_blur_auto(c->blur_impl, c->stream, P, tm, (const OrbxTileDesc*)c->s_tiles.p, (int)t.size(), 1,
                              (const uint8_t*)c->s_img_a.p, (uint8_t*)c->s_img_b.p, 0, kind));
   HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride, c->s_img_b.p, pitch, width, height, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2104,7 +2104,7 @@ int orbx_build_pyramid_level(orbx_ctx* c, const uint8_t* image, int width, int h
   HIPCHK(c, hipMemcpy2DAsync(c->d_in, width, image, stride, width, height, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, launch_pyramid_auto(c, c->stream, 1, c->d_in, width, (size_t)width * height));
   if (blur_enabled(c))
-    HIPCHK(c, launch_blur_auto(c->stream, P, c->tm_blur, c->d_tiles_blur, c->blur_tiles_count, 1, c->d_pyr,
+    HIPCHK(c, launch_blur_auto(c->blur_impl, c->stream, P, c->tm_blur, c->d_tiles_blur, c->blur_tiles_count, 1, c->d_pyr,
                                c->d_pyr_blur,
                                c->p.blur_levels == ORBX_BLUR_UPPER ? 1 : 0, c->p.blur_kind));
   const OrbxLevel& L = P.L[level];
