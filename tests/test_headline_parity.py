@@ -31,6 +31,9 @@ def oracle_on(frames, pk, threads=16):
 
 
 def compare(res, refs, full=True):
+    # (copies: a zero-copy view of the pinned mirror dangles once the context is closed, and pytest prints the locals
+    # of a failed assertion after that)
+    res = {k: (None if v is None else np.array(v)) for k, v in res.items()}
     for i, ref in enumerate(refs):
         n = int(res["counts"][i])
         assert n == len(ref["kps"]), (i, n, len(ref["kps"]))
