@@ -149,8 +149,8 @@ def test_compact_prefetch_equals_full_view(pkg, batches256, oracle256):
         # the ring holds four blocks: views reach up to three batches back
         for _ in range(2):
             c.batch_device(d.data_ptr(), n, W, H)
-        for back in (0, 1, 2, 3):
-            compare(c.batch_host_view(previous=back), oracle256[0][:n])
+        for back in (0, 1, 2, 3):  # (the block three batches back still holds the compact copy made above)
+            compare(c.batch_host_view(previous=back), oracle256[0][:n], full=back < 3)
 
 
 def test_config4_1080p_as_a_batch(pkg):
