@@ -1355,7 +1355,8 @@ __global__ __launch_bounds__(64 * DESC_NW, DESC_OCC) void k_describe2(OrbxPlan p
       for (int k = 0; k < DESC_NLD; k++) {
         regs[j][k] = 0;
         if (lane + 64 * k < DESC_ROWS * (DESC_PITCH / 4))
-          regs[j][k] = *reinterpret_cast<const uint32_t*>(jb.img + (base + (uint32_t)(rowk[k] * jb.pitch + 4 * c3[k % 3])));
+          // (full-rate 24-bit multiply: rows < 41, pitch <= 16384 -- v_mul_lo_u32 is a quarter-rate instruction)
+          regs[j][k] = *reinterpret_cast<const uint32_t*>(jb.img + (base + (__umul24((uint32_t)rowk[k], (uint32_t)jb.pitch) + 4u * (uint32_t)c3[k % 3])));
       }
     } else {
       desc_fetch_patch(jb, lane, regs[j], offs[j]);
@@ -1383,10 +1384,10 @@ __global__ __launch_bounds__(64 * DESC_NW, DESC_OCC) void k_describe2(OrbxPlan p
           X = __builtin_amdgcn_udot4(z, mw[k % 3].x, X, false);
           const uint32_t rs = __builtin_amdgcn_udot4(z, mw[k % 3].y, 0u, false);
           S += rs;
-          M += (uint32_t)rowk[k] * rs;
+          M += __umul24((uint32_t)rowk[k], rs);  // (rows < 41, rs <= 1020: the full-rate 24-bit multiply-add)
         }
-        m10 = wave_sum((int)X - pr * (int)S);
-        m01 = wave_sum((int)M - DESC_R * (int)S);
+        m10 = wave_sum((int)X - __mul24(pr, (int)S));  // (S <= 8 x 1020, pr <= 20: 24-bit operands)
+        m01 = wave_sum((int)M - __mul24(DESC_R, (int)S));
       }
       if (lane == 0) {
         s_m[q][0] = m10;
