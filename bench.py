@@ -360,10 +360,12 @@ def main():
         # >= 8 distinct resident batches (the graph cache holds 8 batch shapes: (input, result block) pairs)
         nb8 = 8
         base_first = pkg.shard.frame_range(rank, world, len(batches) * B)[0] + world * len(batches) * B
-        while len(batches) < nb8:
+        while len(batches) < nb8:  # (the extra batches are generated on the device: nothing compares them with the oracle)
             k = len(batches)
-            gen = pkg.streams.stream_a if args.workload == "kitti" else (lambda n, first: pkg.streams.stream_b(n, H, W, first))
-            batches.append((torch.from_numpy(gen(B, first=base_first + k * B)).to(dev), B))
+            if args.workload == "kitti":
+                batches.append((pkg.streams.stream_a_device(torch, base_first + k * B, B, dev), B))
+            else:
+                batches.append((torch.from_numpy(pkg.streams.stream_b(B, H, W, base_first + k * B)).to(dev), B))
         for i in range(nb8):
             submit(i)
         ctx.wait()
