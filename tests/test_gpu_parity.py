@@ -427,6 +427,33 @@ def test_scale_factors_and_resize_paths(pkg, kitti1):
             check_whole(c.detect_and_compute(img), O.detect_and_compute_gpu(img, op))
 
 
+@pytest.mark.parametrize("w", [1241, 1022, 643, 600, 250])
+def test_staged_resize_levels(pkg, w):
+    """Levels of scale 2..3.2 through the batched path: k_pyrblur stages the strip's span of the two source rows in
+    LDS (spans that end with the source row for every width mod 4 -- the frame's buffer descriptor zeroes a dword
+    that straddles the frame's last byte --, spans of fewer and of more than 64 8-byte chunks, one and several
+    strips per level, a single-strip level that must fall back to the 2-byte gathers).  Noise frames and per-level
+    caps above the number of corners of the staged level: every pixel of it matters."""
+    h = 200
+    for sf in (2.1, 2.6, 3.1):
+        kw = dict(nfeatures=2800, nlevels=3, scale_factor=sf, threshold=25, blur_levels=2)
+        p = pkg.default_params("gpu", max_width=w, max_height=h, max_batch=2, **kw)
+        op = O.gpu_params(**kw)
+        frames = np.stack([synth(31 * w + int(10 * sf), h, w, "noise"), synth(w + int(10 * sf), h, w, "rects")])
+        with pkg.Context(p) as c:
+            cap = c.plan(w, h)["out_capacity"]
+            c.batch_host(frames)
+            r = c.batch_fetch(0, 2, cap)
+            for i in range(2):
+                ref = O.detect_and_compute_gpu(frames[i], op)
+                n = int(r["counts"][i])
+                got = dict(count=n, kps=r["kps"][i, :n], kps_level=r["kps_level"][i, :n], levels=r["levels"][i, :n],
+                           angles=r["angles"][i, :n], responses=r["responses"][i, :n], desc=r["desc"][i, :n])
+                check_whole(got, ref)
+                lv1 = got["levels"] == 1
+                assert 15 <= lv1.sum() < c.plan(w, h)["quota"][1], (w, sf, lv1.sum())  # the level has corners, none cut
+
+
 def test_random_frames_many(pkg):
     """A few hundred keypoint-rich random frames through the batched path vs the oracle (rare-event hunting:
     rounding ties in the rotation, ties in NMS and in the Harris ranking)."""
@@ -579,7 +606,7 @@ def test_pipelined_result_fetch(pkg, kitti0, kitti1):
 def test_fused_pyramid_blur_equals_separate_kernels(pkg, shape):
     """Blur on every level: the batched path builds and blurs the pyramid in one kernel (k_pyrblur); with
     orbx_set_fused_pyramid_blur(0) the two kernels run separately.  Same results, equal to the oracle
-    (strip / lane / band boundaries of both kernels, both resize gather modes: 8 levels reach scale 3.6)."""
+    (strip / lane / band boundaries of both kernels, all three resize modes of scale > 2: 8 levels reach scale 3.6)."""
     h, w = shape
     img = synth(h * 7 + w, h, w, "noise" if min(h, w) < 100 else "rects")
     nl = 8 if min(h, w) >= 60 else 4

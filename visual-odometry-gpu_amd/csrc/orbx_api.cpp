@@ -374,7 +374,7 @@ void build_frame_tiles(const OrbxPlan& plan, int tw, int th, bool pyramid_fields
     const OrbxLevel& L = plan.L[l];
     // pyramid tiles: 8 rows per wave where a lane keeps only 4 registers per row in flight
     // (level 0 copy, 8-byte-window levels), else 4
-    const int rpw = pyramid_fields ? ((l == 0 || L.win8) ? 8 : 4) : 0;
+    const int rpw = pyramid_fields ? ((l == 0 || L.win8 == 1) ? 8 : 4) : 0;
     if (pyramid_fields) th = 4 * rpw;
     const int ntx = (L.pitch + tw - 1) / tw, nty = (L.h + th - 1) / th;
     for (int ty = 0; ty < nty; ty++)
@@ -390,7 +390,7 @@ void build_frame_tiles(const OrbxPlan& plan, int tw, int th, bool pyramid_fields
         if (pyramid_fields) {
           d.u0 = L.xtab_off;
           d.u1 = L.ytab_off;
-          d.u2 = L.win8;
+          d.u2 = L.win8 == 1;  // (k_pyramid2 knows the one-window mode only)
         }
         d.img_off = (uint64_t)L.img_off;
         out->push_back(d);
@@ -500,7 +500,7 @@ void build_pyrblur_tiles(const OrbxPlan& plan, int max_rows, std::vector<OrbxTil
   }
   if (heavy_first) {
     // estimated instructions per strip row: level 0 copies, the 8-byte-window levels resize, the others gather
-    auto cost = [](const OrbxTileDesc& d) { return (d.f + 4) * (d.l == 0 ? 35 : d.u2 ? 80 : 90); };
+    auto cost = [](const OrbxTileDesc& d) { return (d.f + 4) * (d.l == 0 ? 35 : d.u2 == 1 ? 80 : 90); };
     std::stable_sort(out->begin(), out->end(),
                      [&](const OrbxTileDesc& a, const OrbxTileDesc& b) { return cost(a) > cost(b); });
   }
@@ -637,6 +637,22 @@ void make_taps(OrbxPlan& plan, std::vector<OrbxResizeTap>* taps) {
       for (int dx = L.w & ~3; dx < L.w && ok; dx++)
         ok = (*taps)[L.xtab_off + dx].ofs + 1 - (*taps)[L.xtab_off + (L.w & ~3)].ofs <= 7;
       plan.L[l].win8 = ok ? 1 : 0;
+      if (!ok && plan.w0 >= 8) {
+        // ... or stage the source rows of a strip through LDS (k_pyrblur): every 256-pixel strip of the level must
+        // read its pairs from at most ORBX_PYR_STAGE_BYTES of a source row (scales up to ~3.2; orbx_internal.h).  The span starts at
+        // the first pair, moved down so that its dwords END with the source row -- the buffer descriptor of the
+        // frame returns zero for a dword that straddles the frame's last byte, which the dword holding the last
+        // bytes of the last source row would do at any other alignment; where that is impossible (first strip: the
+        // span cannot start before the row) the strip must not reach that dword.
+        bool ok3 = true;
+        for (int x0 = 0; x0 < L.w && ok3; x0 += ORBX_PYRBLUR_TW) {
+          const int ofs_first = (*taps)[L.xtab_off + x0].ofs, ofs_last = (*taps)[L.xtab_off + std::min(x0 + 255, L.w - 1)].ofs;
+          const int want = ofs_first - ((ofs_first - plan.w0) & 3), span0 = std::max(want, 0);
+          ok3 = ofs_last + 2 - span0 <= ORBX_PYR_STAGE_BYTES;
+          if (want < 0 && (plan.w0 & 3) && ofs_last + 2 > (plan.w0 & ~3)) ok3 = false;
+        }
+        if (ok3) plan.L[l].win8 = 3;
+      }
     }
     for (int dy = 0; dy < L.h; dy++) {
       float fy = (float)((dy + 0.5) * scale_y - 0.5);

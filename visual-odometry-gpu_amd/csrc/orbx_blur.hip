@@ -402,13 +402,22 @@ struct PyrSrc {
   // (plus its wait) sat in front of every row's gathers
   int yt_ofs;
   uint32_t yt_cc;               // c0 | c1 << 16
+  int n8;                       // staged mode: 8-byte chunks of a source row the strip needs (<= 128)
 };
 struct PyrLane {  // x taps of the lane's four pixels
   uint32_t ofs[4], cc[4], sel[4], base;
+  uint32_t lds_a[4];  // staged mode: dword-aligned byte offset of pixel k's pair within a staged source row
 };
+// staged mode: per wave two source rows of ORBX_PYR_STAGE_BYTES (+ 8: the pair of the row's last byte is read as
+// two dwords)
+#define PYR_STAGE_ROW (ORBX_PYR_STAGE_BYTES + 8)
 
 // MODE 0: level 0 (one unaligned dword of the frame); 1: resize through one 8-byte window per source
-// row (scale <= 2, host-verified per level); 2: resize with four 2-byte pair gathers per source row
+// row (scale <= 2, host-verified per level); 2: resize with four 2-byte pair gathers per source row; 3: the same
+// pairs read from LDS, where the strip's span of the two source rows has been STAGED with four coalesced 8-byte
+// loads per output row (scale <= ~3.2, host-verified: OrbxLevel::win8 == 3).  The gathers of mode 2 are 8
+// vector-memory instructions with 64 scattered addresses each per output row, and they, not the arithmetic, were
+// what its strips took 1.5x the window mode's time per pixel for (with a quarter of them: the window mode's time)
 template <int MODE>
 struct PyrRaw {
   uint32_t q0[MODE == 0 ? 1 : MODE == 1 ? 2 : 4], q1[MODE == 0 ? 1 : MODE == 1 ? 2 : 4];
@@ -449,6 +458,31 @@ __device__ __forceinline__ void pyr_issue(const PyrSrc& P, const PyrLane& T, int
     R.q0[1] = a.y;
     R.q1[0] = b.x;
     R.q1[1] = b.y;
+  } else if (MODE == 3) {
+    // lane i: bytes [8 i, 8 i + 8) and [512 + 8 i, 512 + 8 i + 8) of the strip's span of both source rows, the
+    // lanes past the span's end switched off (the texture addresser takes a cycle per four lane-dwords, coalesced
+    // or not: what these rows cost is the number of active lanes x dwords); their registers keep the last row's
+    // values and land in a part of the staging row nobody reads
+    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    if (lane < P.n8) {
+      const v2u a = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(P.rsrc, T.base, so0, 0));
+      const v2u b = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(P.rsrc, T.base, so1, 0));
+      R.q0[0] = a.x;
+      R.q0[MODE == 3 ? 1 : 0] = a.y;
+      R.q1[0] = b.x;
+      R.q1[MODE == 3 ? 1 : 0] = b.y;
+    }
+    if (P.n8 > 64) {  // wave-uniform
+      if (lane + 64 < P.n8) {
+        const v2u a2 = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(P.rsrc, T.base + 512u, so0, 0));
+        const v2u b2 = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(P.rsrc, T.base + 512u, so1, 0));
+        R.q0[MODE == 3 ? 2 : 0] = a2.x;
+        R.q0[MODE == 3 ? 3 : 0] = a2.y;
+        R.q1[MODE == 3 ? 2 : 0] = b2.x;
+        R.q1[MODE == 3 ? 3 : 0] = b2.y;
+      }
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < (MODE == 2 ? 4 : 0); k++) {
@@ -460,17 +494,44 @@ __device__ __forceinline__ void pyr_issue(const PyrSrc& P, const PyrLane& T, int
 }
 
 // the row's dword of four level pixels (OpenCV: ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2)
+struct __attribute__((packed, aligned(4))) uint2_a4 {
+  uint32_t x, y;
+};
+// staged mode: the loaded spans of the two source rows -> the wave's staging buffer (wave-private: no barrier)
+__device__ __forceinline__ void pyr_stage(const PyrSrc& P, const PyrRaw<3>& R, uint8_t* stage) {
+  const int lane8 = (threadIdx.x & 63) * 8;
+  *reinterpret_cast<uint2*>(stage + lane8) = make_uint2(R.q0[0], R.q0[1]);
+  *reinterpret_cast<uint2*>(stage + PYR_STAGE_ROW + lane8) = make_uint2(R.q1[0], R.q1[1]);
+  if (P.n8 > 64) {  // wave-uniform
+    if ((int)(threadIdx.x & 63) + 64 < P.n8) {  // (the staging row ends with the longest span: ORBX_PYR_STAGE_BYTES)
+      *reinterpret_cast<uint2*>(stage + 512 + lane8) = make_uint2(R.q0[2], R.q0[3]);
+      *reinterpret_cast<uint2*>(stage + PYR_STAGE_ROW + 512 + lane8) = make_uint2(R.q1[2], R.q1[3]);
+    }
+  }
+  wave_lds_sync();
+}
 template <int MODE>
-__device__ __forceinline__ uint32_t pyr_finish(const PyrLane& T, const PyrRaw<MODE>& R) {
+__device__ __forceinline__ uint32_t pyr_finish(const PyrLane& T, const PyrRaw<MODE>& R, uint8_t* stage = nullptr) {
   if (MODE == 0) return R.q0[0];
   uint32_t out = 0;
   const uint32_t bs0 = ((uint32_t)R.b0 << 12) & 0xffffffu, bs1 = ((uint32_t)R.b1 << 12) & 0xffffffu;  // b <= 2048
+  uint32_t selp = T.sel[0];
+  if (MODE == 3) asm volatile("" : "+v"(selp));  // (opaque: or the unpacking is hoisted out of the row loop, into four registers)
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     uint32_t p0, p1;  // the pixel pair as two u16 lanes
     if (MODE == 1) {
       p0 = __builtin_amdgcn_perm(R.q0[1], R.q0[0], T.sel[k]);
       p1 = __builtin_amdgcn_perm(R.q1[1], R.q1[0], T.sel[k]);
+    } else if (MODE == 3) {  // the pair's two aligned dwords of each staged row, the pair cut out by v_perm
+      // (an unaligned 16-bit LDS read per pair is legal on gfx950 and took 4x the LDS time)
+      // (the four selectors of a lane travel as 4-bit fields of ONE register, sel_k = 0x0c000c00 | ((sel[0] >> 4 k) &
+      // 0x00070003): the kernel has no registers to spare, and spilling them costs more than the unpacking)
+      const uint2_a4 v0 = *reinterpret_cast<const uint2_a4*>(stage + T.lds_a[k]);
+      const uint2_a4 v1 = *reinterpret_cast<const uint2_a4*>(stage + PYR_STAGE_ROW + T.lds_a[k]);
+      const uint32_t sel = ((selp >> (4 * k)) & 0x00070003u) | 0x0c000c00u;
+      p0 = __builtin_amdgcn_perm(v0.y, v0.x, sel);
+      p1 = __builtin_amdgcn_perm(v1.y, v1.x, sel);
     } else {
       p0 = __builtin_amdgcn_perm(R.q0[MODE == 2 ? k : 0], R.q0[MODE == 2 ? k : 0], 0x0c010c00u);
       p1 = __builtin_amdgcn_perm(R.q1[MODE == 2 ? k : 0], R.q1[MODE == 2 ? k : 0], 0x0c010c00u);
@@ -490,15 +551,22 @@ __device__ __forceinline__ uint32_t pyr_finish(const PyrLane& T, const PyrRaw<MO
 }
 
 template <int MODE, bool PATCH>
-__device__ __forceinline__ void pyrblur_strip(const Blur3Strip& S, const PyrSrc& P, const PyrLane& T) {
+__device__ __forceinline__ void pyrblur_strip(const Blur3Strip& S, const PyrSrc& P, const PyrLane& T,
+                                              uint8_t* stage = nullptr) {
   // Loads in flight per wave: the five rows of a group (modes 0 and 1: <= 4 registers per row), or the
   // next row only (pair-gather mode: 8 registers per row).  With <= 64 registers the kernel keeps 8
   // waves per SIMD, i.e. ALL waves of a 64-frame KITTI batch are resident at once (7.4 per SIMD): at
   // 6 per SIMD the second, partly filled round of waves cost 40 % (100 us instead of 70).
-  constexpr int NB = MODE == 2 ? 2 : 5;
+  // (staged mode: the next row only as well, and its registers are free again once they are in LDS)
+  constexpr bool ROWWISE = MODE == 2 || MODE == 3;
+  constexpr int NB = MODE == 3 ? 1 : MODE == 2 ? 2 : 5;
   const uint32_t k4 = pk_opaque(0x00040004u), k6 = pk_opaque(0x00060006u);
   uint32_t he[5], ho[5];
   PyrRaw<MODE> raw[NB];
+  if (MODE == 3) {  // (the switched-off lanes of pyr_issue never write theirs)
+#pragma unroll
+    for (int k = 0; k < (MODE == 3 ? 4 : 0); k++) raw[0].q0[k] = raw[0].q1[k] = 0;
+  }
   // input row r of the strip is level row y0 - 2 + r; output row y0 + r - 4 is complete after row r
   const int nr = S.yend - S.y0 + 4;  // input rows
   // (rows past the strip, in the last group, are computed from clamped indices and never stored)
@@ -507,15 +575,27 @@ __device__ __forceinline__ void pyrblur_strip(const Blur3Strip& S, const PyrSrc&
     pyr_issue<MODE>(P, T, rr, reflect101_s(S.y0 - 2 + rr, S.h), R);
   };
   auto hpass = [&](int rb, int k) {
+    if (MODE == 3) {
+      // row rb + k: registers -> LDS, the next row's loads into the same registers, this row's pairs from LDS.
+      // (ONE staging buffer per wave: a wave's LDS operations execute in order, the next row's writes cannot
+      // overtake this row's reads)
+      PyrRaw<MODE> cur;
+      cur.b0 = raw[0].b0;
+      cur.b1 = raw[0].b1;
+      if constexpr (MODE == 3) pyr_stage(P, raw[0], stage);
+      if (k < 4) issue(rb + k + 1, raw[0]);
+      blur3_h<PATCH>(S, pyr_finish<MODE>(T, cur, stage), 0u, k4, k6, he[k], ho[k]);
+      return;
+    }
     if (MODE == 2 && k < 4) issue(rb + k + 1, raw[(k + 1) & 1]);
-    blur3_h<PATCH>(S, pyr_finish<MODE>(T, raw[MODE == 2 ? (k & 1) : k]), 0u, k4, k6, he[k], ho[k]);
+    blur3_h<PATCH>(S, pyr_finish<MODE>(T, raw[MODE == 2 ? (k & 1) : MODE == 3 ? 0 : k], stage), 0u, k4, k6, he[k], ho[k]);
   };
   auto fetch_group = [&](int rb) {
-    if (MODE == 2) {
+    if (ROWWISE) {
       issue(rb, raw[0]);
     } else {
 #pragma unroll
-      for (int k = 0; k < 5; k++) issue(rb + k, raw[MODE == 2 ? 0 : k]);
+      for (int k = 0; k < 5; k++) issue(rb + k, raw[ROWWISE ? 0 : k]);
     }
   };
   fetch_group(0);
@@ -640,6 +720,7 @@ __global__ __launch_bounds__(256, 8) void k_pyrblur(const OrbxTileDesc* __restri
   P.h = h;
   P.yt_ofs = 0;
   P.yt_cc = 0;
+  P.n8 = 0;
   if (d.l > 0) {  // lane r: the y tap of the strip's input row r (a band has at most 58 rows: r <= 63)
     const OrbxResizeTap ty = taps[d.u1 + reflect101_s(S.y0 - 2 + min(lane, S.yend - S.y0 + 5), h)];
     P.yt_ofs = ty.ofs;
@@ -647,7 +728,7 @@ __global__ __launch_bounds__(256, 8) void k_pyrblur(const OrbxTileDesc* __restri
   }
   PyrLane T;
 #pragma unroll
-  for (int k = 0; k < 4; k++) T.ofs[k] = T.cc[k] = T.sel[k] = 0;
+  for (int k = 0; k < 4; k++) T.ofs[k] = T.cc[k] = T.sel[k] = T.lds_a[k] = 0;
   T.base = 0;
   if (d.l == 0) {
     if (patch)
@@ -663,7 +744,27 @@ __global__ __launch_bounds__(256, 8) void k_pyrblur(const OrbxTileDesc* __restri
     T.ofs[0] = t01.x; T.ofs[1] = t01.z; T.ofs[2] = t23.x; T.ofs[3] = t23.z;
     T.cc[0] = t01.y; T.cc[1] = t01.w; T.cc[2] = t23.y; T.cc[3] = t23.w;
   }
-  if (d.u2) {
+  if (d.u2 == 3) {
+    // staged rows: the strip's span of a source row starts at the (8-byte aligned) pair of the strip's first pixel
+    __shared__ __attribute__((aligned(8))) uint8_t s_stage[4][2 * PYR_STAGE_ROW];
+    // (scalar loads), aligned so that the dwords of the span end with the source row: the frame's buffer descriptor
+    // returns ZERO for a dword that straddles the frame's last byte (orbx_api.cpp, build_plan, verifies the level)
+    const int ofs_first = taps[d.u0 + x_lo].ofs, ofs_last = taps[d.u0 + min(x_lo + 255, w - 1)].ofs;
+    const uint32_t span0 = (uint32_t)max(ofs_first - ((ofs_first - w0) & 3), 0);
+    P.n8 = __builtin_amdgcn_readfirstlane((ofs_last + 2 - (int)span0 + 7) >> 3);
+    T.base = span0 + (uint32_t)lane * 8u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t rel = (x >= 0 && x < w) ? T.ofs[k] - span0 : 0u;  // <= ORBX_PYR_STAGE_BYTES - 2 (host-verified)
+      T.lds_a[k] = rel & ~3u;
+      const uint32_t sb = rel & 3u;  // of {dword a, dword a + 1}: bytes sb, sb + 1
+      T.sel[0] |= (sb | ((sb + 1) << 16)) << (4 * k);
+    }
+    if (patch)
+      pyrblur_strip<3, true>(S, P, T, s_stage[wave]);
+    else
+      pyrblur_strip<3, false>(S, P, T, s_stage[wave]);
+  } else if (d.u2) {
     // the window start is clamped so that it never reads past the source row
     T.base = min(T.ofs[0], (uint32_t)(w0 - 8));
 #pragma unroll

@@ -27,7 +27,7 @@ struct OrbxLevel {
   int32_t ytab_off;  // first entry of this level's resize y-table
   float scale;       // (float)pow(scaleFactor, l)  src/orb.cpp:95
   int32_t out_off;   // first STATIC selection slot of this level = sum of the lower levels' quotas
-  int32_t win8;      // resize: the 4 source pairs of any aligned group of 4 outputs fit one 8-byte window
+  int32_t win8;      // resize: 1: the 4 source pairs of any aligned group of 4 outputs fit one 8-byte window; 3: a strip's source span fits the LDS staging rows of k_pyrblur; 0: neither (2-byte gathers)
   // 0: classic mask rows (bit x & 63 of word x >> 6).  > 0: STRIP layout of the streaming FAST kernel
   // (orbx_fast4.hip): 4 words per strip and row, word 4 s + q of a row holds pixels mask_strip_px * s + 64 q + bit
   // (a strip's first / last halo pixels are zero bits), so x = (xw >> 2) * mask_strip_px + (xw & 3) * 64 + bit
@@ -142,6 +142,11 @@ constexpr int orbx_fast4_strips(int w, int nms_radius) {
 #define ORBX_BLUR4_RH 96
 // fused pyramid + blur: the halo dwords are computed, not loaded, so lanes 0 / 63 are halo-only
 #define ORBX_PYRBLUR_TW 248
+// LDS staging of the source rows of the levels whose pairs do not fit the 8-byte window (scale > 2): bytes of a
+// source row a strip may need.  (Measured per level of 1241x376, 256 frames: scale 2.1: 41 us staged / 56 us with
+// 2-byte gathers, 2.5: 35 / 43, 3.0: 27 / 32, 3.5 (896 bytes): 30 / 29 -- the staged loads cost the texture
+// addresser a cycle per four lane-dwords like any other, and at 8 x 104 bytes they are as many as the gathers'.)
+#define ORBX_PYR_STAGE_BYTES 832
 // rows per band of the fused kernel: the y taps of a band's input rows (rows + 6) sit one per lane
 #define ORBX_PYRBLUR_RH 58
 #define ORBX_PYRBLUR_RH_SMALL 12  // few frames per call: many short waves instead
