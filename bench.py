@@ -507,27 +507,43 @@ def main():
 
     # ---- D2H-inclusive rate (reported beside `value`, never as it): the result block of batch i is copied on
     # the context's copy stream while batch i+1 runs (orbx_batch_prefetch / orbx_batch_fetch_previous)
-    fps_d2h = fps_d2h_blocking = None
+    fps_d2h = fps_d2h_blocking = fps_d2h_ref = None
     if not args.only_timed:
-        # production shape (pipelined lanes) + orbx_batch_prefetch_compact: counts, keypoints, orientations and
+        # production shape (pipelined lanes) + orbx_batch_prefetch_compact: counts, packed keypoints, orientations and
         # descriptors of every batch land in the pinned mirror while the next batch runs and are read there in place
         nd = max(steps, 10)
         if pipelined:
             ctx.set_pipelined_batches(True)
-        # (measured: 11.2 MB per 256-frame batch at ~18 GB/s take about as long as the step itself -- this rate is the
-        # host link's, and a consumer that lags two batches instead of one gets less, not more)
+        # orbx_set_host_results: the describe kernel writes the compact record (40 B per slot) into the pinned mirror
+        # itself, so nothing is copied afterwards and orbx_batch_prefetch_compact only marks the block.  Measured
+        # (tools/d2h_lag.py): the host link takes ~17 GB/s of such writes next to the kernels of the other lane (a
+        # lone copy: 32 GB/s) -- ~430 k frames/s whatever the batch size, 0.99 of `value` at 256 frames per step and
+        # 0.92 at 1024.  Copying the record after the batch instead (orbx_batch_prefetch_compact without it, the
+        # runtime's copy kernel on the copy stream) gives 0.93-0.95 when the copy is enqueued after the wait for
+        # the previous batch's results, and between 0.7 and 0.99 -- depending on the process's other streams -- when
+        # it is enqueued right behind the batch, where it sits behind a wait for the batch's end.
+        for i in range(2):
+            submit(i)
+        ctx.wait()
+        t1 = time.perf_counter()
+        for i in range(nd):  # the same loop with the results left on the device, for the ratio (it is not `value`)
+            submit(i)
+        ctx.wait()
+        fps_d2h_ref = world * nd * batches[0][1] / (time.perf_counter() - t1)
+        ctx.set_host_results(True)
         submit(0)
         ctx.batch_prefetch(compact=True)
         t1 = time.perf_counter()
         done = kp_seen = 0
         for i in range(1, nd + 1):
             n = submit(i)
+            ctx.batch_prefetch(compact=True)
             hv = ctx.batch_host_view(previous=1)  # batch i-1, zero-copy from the pinned mirror
             done += len(hv["counts"])
             kp_seen += int(hv["counts"].sum())
-            ctx.batch_prefetch(compact=True)
         ctx.wait()
         fps_d2h = world * done / (time.perf_counter() - t1)
+        ctx.set_host_results(False)
         if pipelined:
             ctx.set_pipelined_batches(False)
         t1 = time.perf_counter()
@@ -706,7 +722,7 @@ def main():
             "stage_ms_per_step_unfused": unfused_ms,
             "value_full_work": value_full_work, "value_sustained": value_sustained, "sustained": sustained_info,
             "fps_with_d2h": fps_d2h, "fps_with_d2h_blocking_fetch": fps_d2h_blocking,
-            "d2h_bytes_per_frame": 4 + 44 * cap, "d2h_GBps_at_fps_with_d2h": (fps_d2h or 0) * (4 + 44 * cap) / 1e9,
+            "fps_same_loop_without_copies": fps_d2h_ref, "d2h_bytes_per_frame": 4 + 40 * cap, "d2h_GBps_at_fps_with_d2h": (fps_d2h or 0) * (4 + 40 * cap) / 1e9,
             "fps_two_contexts_alternating": two_ctx_fps,
             "single_frame_host_to_host": single,
             "lk_track": lk,

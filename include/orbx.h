@@ -142,6 +142,7 @@ typedef struct {
   const orbx_descriptor* descriptors; /* [n][slot_capacity] */
   int32_t slot_capacity;
   int32_t n;
+  const uint32_t* keypoints16;      /* [n][slot_capacity] the same level-0 coords packed, x | y << 16 (both <= 16384) */
 } orbx_batch_view;
 int orbx_batch_results_device(orbx_ctx* ctx, orbx_batch_view* view);
 
@@ -157,18 +158,32 @@ int orbx_batch_fetch(orbx_ctx* ctx, int first, int n, int32_t* counts, orbx_keyp
  * blocks, one per batch in turn:
  *   orbx_detect_and_compute_batch_device(batch i);  orbx_batch_prefetch();
  *   orbx_detect_and_compute_batch_device(batch i+1);          -- kernels overlap the copy of i
- *   orbx_batch_fetch_previous(...)  -> results of batch i (waits for the copy only);  ...
+ *   orbx_batch_fetch_previous(...)  -> results of batch i (waits for the copy only);  orbx_batch_prefetch();  ...
+ * (The copy is the runtime's copy kernel behind a wait for the batch's end.  Enqueued once the previous batch's
+ * results have been read, as above, it costs 5-7 % of the frame rate; enqueued right behind its batch it may sit in
+ * a hardware queue in front of the other lane's kernels for the whole batch -- measured between 0.7 and 0.99 of the
+ * rate without copies, depending on the streams the process has.  orbx_set_host_results below needs no copy at all.)
  * orbx_batch_prefetch starts an asynchronous D2H copy of the last batch's block into its pinned
  * mirror on the context's copy stream; orbx_batch_fetch / _previous then wait for that copy
  * instead of copying.  The results of batch i stay in its block until batch i+4 is submitted; the views
  * reach batch i (the last one) and batch i-1. */
 int orbx_batch_prefetch(orbx_ctx* ctx);
 /* The same for consumers that want what the reference's detectAndCompute returns and nothing else (keypoints,
- * orientations, descriptors: include/orb.hpp:37): only the counts | keypoints | orientations | descriptors sections
- * of the block are copied -- 44 instead of 60 bytes per keypoint slot, which is what keeps the copy under the host
- * link's rate at the benchmark's frame rate.  orbx_batch_results_host then reports responses / levels / level_kps
- * as NULL; a fetch that asks for them copies the remaining sections first (blocking). */
+ * orientations, descriptors: include/orb.hpp:37): only the counts | keypoints16 | orientations | descriptors
+ * sections of the block are copied, the keypoints as packed 16-bit pairs -- 40 instead of 64 bytes per keypoint
+ * slot, which is what keeps the copy under the host link's rate at the benchmark's frame rate.
+ * orbx_batch_results_host then reports keypoints / responses / levels / level_kps as NULL (keypoints16 is always
+ * there); a fetch unpacks the keypoints from keypoints16, and one that asks for responses / levels / level_kps
+ * copies the remaining sections first (blocking). */
 int orbx_batch_prefetch_compact(orbx_ctx* ctx);
+/* Host results without a copy (default off): with enable = 1 the kernel that finishes a batch (orientation + BRIEF)
+ * writes the compact record -- counts | keypoints16 | orientations | descriptors -- of every keypoint into the block's
+ * PINNED HOST mirror as well, in coalesced stores that travel the host link while the kernel runs.
+ * orbx_batch_prefetch_compact then only marks the block (nothing is copied, no copy kernel competes with the next
+ * batch), orbx_batch_prefetch copies the other sections, and the host views / fetches deliver the same bytes as
+ * before.  The device-side result block is written as always.  (The reference copies every stage's results back
+ * with a blocking cudaMemcpy: src/cuda/Fast.cu:238-239, src/cuda/Brief.cu:131.)  bench.py: fps_with_d2h. */
+int orbx_set_host_results(orbx_ctx* ctx, int enable);
 /* Zero-copy host view of a result block: pointers into the context's PINNED mirror of the last batch
  * (previous = 0) or of the batch `previous` calls before it (1..3: the ring has four blocks), same layout
  * as the device view (fixed stride `slot_capacity` entries per frame; only the first counts[f] entries of

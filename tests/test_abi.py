@@ -40,7 +40,7 @@ def test_pod_layouts(pkg):
     o = pkg.orbx
     assert C.sizeof(o.Params) == 16 * 4
     assert o.Params.scale_factor.offset == 4 and o.Params.harris_k.offset == 32 and o.Params.device.offset == 60
-    assert C.sizeof(o.BatchView) == 7 * 8 + 8
+    assert C.sizeof(o.BatchView) == 7 * 8 + 8 + 8 and o.BatchView.keypoints16.offset == 64
 
 
 def test_default_params_are_the_reference_defaults(pkg):

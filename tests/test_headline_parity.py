@@ -37,7 +37,11 @@ def compare(res, refs, full=True):
     for i, ref in enumerate(refs):
         n = int(res["counts"][i])
         assert n == len(ref["kps"]), (i, n, len(ref["kps"]))
-        assert np.array_equal(res["kps"][i, :n], ref["kps"]), i
+        if res.get("kps") is not None:
+            assert np.array_equal(res["kps"][i, :n], ref["kps"]), i
+        if res.get("kps16") is not None:  # (the packed pairs of the host views; the only ones of a compact copy)
+            assert np.array_equal(res["kps16"][i, :n].astype(np.int32), ref["kps"]), i
+        assert res.get("kps") is not None or res.get("kps16") is not None
         assert np.allclose(res["angles"][i, :n], ref["angles"], atol=1e-4, rtol=0), i
         assert np.array_equal(res["desc"][i, :n], ref["desc"]), i
         if full:
@@ -119,8 +123,9 @@ def test_caller_stream_batches_between_pipelined_ones(pkg, batches256, oracle256
 
 
 def test_compact_prefetch_equals_full_view(pkg, batches256, oracle256):
-    """orbx_batch_prefetch_compact copies counts | keypoints | orientations | descriptors only; what it delivers equals
-    the full copy, the other sections read NULL, and a fetch that asks for them gets them all the same."""
+    """orbx_batch_prefetch_compact copies counts | packed keypoints | orientations | descriptors only (40 bytes per
+    slot); what it delivers equals the full copy, the other sections read NULL, a fetch unpacks the keypoints and one
+    that asks for the other sections gets them all the same."""
     import torch
 
     n = 32
@@ -132,12 +137,14 @@ def test_compact_prefetch_equals_full_view(pkg, batches256, oracle256):
         c.batch_device(d.data_ptr(), n, W, H)
         c.batch_prefetch(compact=True)
         hv = c.batch_host_view()
-        assert hv["responses"] is None and hv["levels"] is None and hv["kps_level"] is None
+        assert hv["responses"] is None and hv["levels"] is None and hv["kps_level"] is None and hv["kps"] is None
+        assert hv["kps16"].dtype == np.uint16
         compare(hv, oracle256[0][:n], full=False)
         full = c.batch_fetch(0, n, cap)  # asks for every section: the rest is copied now
         compare(full, oracle256[0][:n])
-        for k in ("counts", "kps", "angles", "desc"):
-            assert np.array_equal(hv[k], full[k] if k == "counts" else full[k]), k
+        for k in ("counts", "angles", "desc"):
+            assert np.array_equal(hv[k], full[k]), k
+        assert np.array_equal(hv["kps16"].astype(np.int32), full["kps"])
         # streaming use: compact copy of batch i overlaps batch i + 1
         c.set_pipelined_batches(True)
         c.batch_device(d.data_ptr(), n, W, H)
@@ -151,6 +158,45 @@ def test_compact_prefetch_equals_full_view(pkg, batches256, oracle256):
             c.batch_device(d.data_ptr(), n, W, H)
         for back in (0, 1, 2, 3):  # (the block three batches back still holds the compact copy made above)
             compare(c.batch_host_view(previous=back), oracle256[0][:n], full=back < 3)
+
+
+@pytest.mark.parametrize("n", [32, 5])
+def test_host_results_written_by_the_describe_kernel(pkg, batches256, oracle256, n):
+    """orbx_set_host_results: the compact record reaches the pinned mirror from the describe kernel itself.  The host
+    views and fetches deliver what the copies delivered -- compact mark, whole block, blocking fetch, pipelined
+    streaming with the ring of four blocks, graph replay and plain launches, both describe variants (n = 5: one
+    keypoint per wave) -- and switching it off again restores the copies."""
+    import torch
+
+    d = [torch.from_numpy(batches256[k][:n]).cuda() for k in range(2)]
+    torch.cuda.synchronize()
+    p = pkg.default_params("gpu", max_width=W, max_height=H, max_batch=n, **PK)
+    with pkg.Context(p) as c:
+        cap = c.plan(W, H)["out_capacity"]
+        c.set_host_results(True)
+        c.batch_device(d[0].data_ptr(), n, W, H)
+        c.batch_prefetch(compact=True)  # (nothing to copy)
+        hv = c.batch_host_view()
+        assert hv["kps"] is None and hv["responses"] is None
+        compare(hv, oracle256[0][:n], full=False)
+        compare(c.batch_fetch(0, n, cap), oracle256[0][:n])  # every section: the others are copied now
+        c.batch_device(d[1].data_ptr(), n, W, H)
+        c.batch_prefetch()  # the whole block: the sections the kernel does not write are copied
+        compare(c.batch_host_view(), oracle256[1][:n])
+        c.batch_device(d[0].data_ptr(), n, W, H)
+        compare(c.batch_host_view(), oracle256[0][:n])  # no prefetch at all
+        c.set_pipelined_batches(True)
+        for i in range(9):  # streaming: mark batch i, read batch i - 1
+            c.batch_device(d[i & 1].data_ptr(), n, W, H)
+            c.batch_prefetch(compact=True)
+            if i:
+                compare(c.batch_host_view(previous=1), oracle256[(i - 1) & 1][:n], full=False)
+        for back in (0, 1, 2, 3):
+            compare(c.batch_host_view(previous=back), oracle256[(8 - back) & 1][:n], full=False)
+        c.set_host_results(False)
+        c.batch_device(d[1].data_ptr(), n, W, H)
+        c.batch_prefetch(compact=True)
+        compare(c.batch_host_view(), oracle256[1][:n], full=False)
 
 
 def test_config4_1080p_as_a_batch(pkg):

@@ -86,6 +86,8 @@ def main():
                 cap = max(c.plan(w, h)["out_capacity"], 1)
                 c.set_fast_early_exit(bool(rng.integers(0, 2)))
                 c.set_fused_pyramid_blur(bool(rng.integers(0, 2)))
+                hostres = bool(rng.integers(0, 2))  # the describe kernel also writes the compact record to the host
+                c.set_host_results(hostres)
                 if big and rng.random() < 0.5:
                     # device-resident batches through the two lanes of the pipelined mode, back to back: the
                     # reversed batch on one lane, the real one on the other
@@ -101,13 +103,21 @@ def main():
                         c.batch_device(dd.data_ptr(), B, w, h, stream=st_)
                     if own is not None and rng.random() < 0.5:  # make sure the LAST batch is the real one on either path
                         c.batch_device(d_img.data_ptr(), B, w, h, stream=own.cuda_stream)
+                    hv = host_record(c) if hostres else None
                     r = c.batch_fetch(0, B, cap)
                     c.set_pipelined_batches(False)
                 else:
                     if big:  # another batch first: rows a skipped strip leaves in the pool must never be read
                         c.batch_host(np.ascontiguousarray(imgs[::-1]))
                     c.batch_host(imgs)
+                    hv = host_record(c) if hostres else None
                     r = c.batch_fetch(0, B, cap)
+                if hv is not None:  # what the kernel wrote into the pinned mirror == what the copy of the block delivers
+                    for i in range(B):
+                        n = int(r["counts"][i])
+                        assert int(hv["counts"][i]) == n and np.array_equal(hv["kps16"][i, :n].astype(np.int32), r["kps"][i, :n]) \
+                            and np.array_equal(hv["angles"][i, :n].view(np.uint32), r["angles"][i, :n].view(np.uint32)) \
+                            and np.array_equal(hv["desc"][i, :n], r["desc"][i, :n]), ("host record", it, i, w, h, kw)
                 single = c.detect_and_compute(imgs[0])
         except pkg.OrbxError as e:
             if e.status == pkg.orbx.ERR_UNSUPPORTED:
@@ -155,6 +165,13 @@ def rowmajor_ref(img, kw):
         out["desc"].append(d)
         out["valid"].append(v)
     return {k: np.concatenate(v) if len(v) else v for k, v in out.items()}
+
+
+def host_record(c):
+    """the compact record of the last batch as the describe kernel wrote it (orbx_set_host_results), copied out"""
+    c.batch_prefetch(compact=True)
+    hv = c.batch_host_view()
+    return {k: np.array(hv[k]) for k in ("counts", "kps16", "angles", "desc")}
 
 
 if __name__ == "__main__":

@@ -36,7 +36,7 @@ struct DevBuf {
 // (keypoints, orientations, descriptors: include/orb.hpp:37) first, so that orbx_batch_prefetch_compact moves one
 // contiguous prefix of `compact` bytes
 struct OutLayout {
-  size_t counts, kp, lkp, angle, resp, level, desc, compact, total;
+  size_t counts, kp16, kp, lkp, angle, resp, level, desc, compact, total;
 };
 
 OutLayout make_out_layout(int n, int cap) {
@@ -48,11 +48,13 @@ OutLayout make_out_layout(int n, int cap) {
     return r;
   };
   const size_t e = (size_t)n * (size_t)cap;
+  // the compact record first (orbx_batch_prefetch_compact copies [0, compact)): 40 bytes per slot
   o.counts = take(sizeof(int32_t) * (size_t)n);
-  o.kp = take(sizeof(orbx_keypoint) * e);
+  o.kp16 = take(sizeof(uint32_t) * e);
   o.angle = take(sizeof(float) * e);
   o.desc = take(sizeof(orbx_descriptor) * e);
   o.compact = off;
+  o.kp = take(sizeof(orbx_keypoint) * e);
   o.lkp = take(sizeof(orbx_keypoint) * e);
   o.resp = take(sizeof(float) * e);
   o.level = take(sizeof(int32_t) * e);
@@ -138,6 +140,9 @@ struct orbx_ctx {
   static constexpr int kBlocks = 4;
   uint8_t* d_outb[kBlocks] = {};
   uint8_t* h_outb[kBlocks] = {};
+  uint8_t* h_outb_dev[kBlocks] = {};   // the device-visible addresses of the pinned mirrors
+  int host_results = 0;                // orbx_set_host_results: the describe kernel writes the compact record to the mirror
+  bool host_written[kBlocks] = {};     // ... and did so for the batch in this block
   OutLayout layoutb[kBlocks] = {};
   int nb[kBlocks] = {};    // frames in the block (0: never written)
   int capb[kBlocks] = {1, 1, 1, 1};  // slots per frame the block was written with
@@ -1000,12 +1005,21 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
   HIPCHK(c, mark(6, false));
   if (P.out_cap <= 0)  // nfeatures too small for any quota: no describe launch, so the counts are zeroed here
     HIPCHK(c, hipMemsetAsync(c->d_out + o.counts, 0, sizeof(int32_t) * (size_t)n, s));
+  // orbx_set_host_results: the kernel also writes the compact record into the pinned mirror of the block
+  OrbxHostRecord hr{};
+  if (c->host_results && P.out_cap > 0) {
+    uint8_t* hd = nullptr;
+    for (int i = 0; i < orbx_ctx::kBlocks; i++)
+      if (c->h_out == c->h_outb[i]) hd = c->h_outb_dev[i];
+    if (hd) hr = OrbxHostRecord{(int32_t*)(hd + o.counts), (uint32_t*)(hd + o.kp16), (float*)(hd + o.angle), (orbx_descriptor*)(hd + o.desc)};
+  }
   HIPCHK(c, orbx_launch_describe(s, P, n, final_pyr(c), c->p.patch_size, c->d_cand_count, c->d_cand, c->d_resp,
                                  (int32_t*)(c->d_out + o.counts), (orbx_keypoint*)(c->d_out + o.lkp),
                                  (float*)(c->d_out + o.resp), (int32_t*)(c->d_out + o.level),
-                                 (orbx_keypoint*)(c->d_out + o.kp), (float*)(c->d_out + o.angle),
+                                 (orbx_keypoint*)(c->d_out + o.kp), (uint32_t*)(c->d_out + o.kp16),
+                                 (float*)(c->d_out + o.angle),
                                  (orbx_descriptor*)(c->d_out + o.desc), two_pass ? c->d_feedback : nullptr,
-                                 two_pass ? const_cast<uint32_t*>(c->h_feedback) : nullptr));
+                                 two_pass ? const_cast<uint32_t*>(c->h_feedback) : nullptr, &hr));
   HIPCHK(c, mark(7, false));
   return ORBX_OK;
 }
@@ -1069,7 +1083,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   }();
   const int tm = c->timing;
   if (use_graph && tm == 0) {
-    const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, (fast_early_on(c) ? 1 : 0) | (fused_pyrblur(c) ? 2 : 0) | (top_rows_wanted(c) ? 4 : 0) | (lanes ? 8 : 0) | (lane << 4),
+    const OrbxGraphKey key{d_frames, frame_stride, n, w, h, row_stride, (fast_early_on(c) ? 1 : 0) | (fused_pyrblur(c) ? 2 : 0) | (top_rows_wanted(c) ? 4 : 0) | (lanes ? 8 : 0) | (lane << 4) | (c->host_results ? 64 : 0),
                            c->plan_serial, blk};
     int gi = -1;
     for (int i = 0; i < orbx_ctx::kGraphs; i++)
@@ -1110,6 +1124,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   c->nb[blk] = n;
   c->capb[blk] = c->plan.out_cap > 0 ? c->plan.out_cap : 1;
   c->copy_pending[blk] = false;
+  c->host_written[blk] = c->host_results && c->plan.out_cap > 0;
   HIPCHK(c, hipEventRecord(c->ev_done[blk], s));
   HIPCHK(c, hipEventRecord(c->ev_pool[lane], s));
   c->pool_stream[lane] = s;
@@ -1395,10 +1410,20 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
   c->out_cap = std::max(M.out_cap, 1);
   {
     const OutLayout o = make_out_layout((int)B, c->out_cap);
-    CREATE_CHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+    {
+      // The copy stream gets the HIGHEST priority -- not for the copies' sake: streams of one priority share a few
+      // hardware queues, and the copy of a batch is enqueued behind a wait for the batch's end.  In a queue shared
+      // with the other lane's stream that wait holds back the other lane's kernels for as long as the batch runs
+      // (measured: the rate with the results on the host then falls from 0.99 to 0.8 of the rate without copies,
+      // depending on which streams the process happens to have created); another priority is another queue.
+      int least = 0, greatest = 0;
+      CREATE_CHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      CREATE_CHK(hipStreamCreateWithPriority(&c->cstream, hipStreamNonBlocking, greatest));
+    }
     for (int i = 0; i < orbx_ctx::kBlocks; i++) {
       CREATE_CHK(hipMalloc((void**)&c->d_outb[i], o.total));
       CREATE_CHK(hipHostMalloc((void**)&c->h_outb[i], o.total, hipHostMallocDefault));
+      CREATE_CHK(hipHostGetDevicePointer((void**)&c->h_outb_dev[i], c->h_outb[i], 0));
       CREATE_CHK(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
       CREATE_CHK(hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
     }
@@ -1483,6 +1508,13 @@ int orbx_wait(orbx_ctx* c) {
   if (!c) return ORBX_ERR_INVALID_ARG;
   HIPCHK(c, hipStreamSynchronize(c->last_stream ? c->last_stream : c->stream));
   HIPCHK(c, lanes_sync(c));
+  return ORBX_OK;
+}
+
+int orbx_set_host_results(orbx_ctx* c, int enable) {
+  DeviceGuard _dg(c);
+  if (!c) return ORBX_ERR_INVALID_ARG;
+  c->host_results = enable ? 1 : 0;  // (takes effect with the next batched call: part of the launch sequence's key)
   return ORBX_OK;
 }
 
@@ -1636,6 +1668,7 @@ int orbx_batch_results_device(orbx_ctx* c, orbx_batch_view* v) {
   const OutLayout& o = c->out_layout;
   v->counts = (const int32_t*)(c->d_out + o.counts);
   v->keypoints = (const orbx_keypoint*)(c->d_out + o.kp);
+  v->keypoints16 = (const uint32_t*)(c->d_out + o.kp16);
   v->level_kps = (const orbx_keypoint*)(c->d_out + o.lkp);
   v->orientations = (const float*)(c->d_out + o.angle);
   v->responses = (const float*)(c->d_out + o.resp);
@@ -1687,7 +1720,10 @@ int fetch_block(orbx_ctx* c, int b, int first, int n, int32_t* counts, orbx_keyp
     const int m = std::min(cnt, capacity);
     if (cnt > capacity) truncated = true;
     const size_t so = (size_t)f * cap, dst = (size_t)i * capacity;
-    if (keypoints) std::memcpy(keypoints + dst, (const orbx_keypoint*)(h + o.kp) + so, sizeof(orbx_keypoint) * m);
+    if (keypoints) {  // (a compact copy holds them packed only: x | y << 16)
+      const uint32_t* k16 = (const uint32_t*)(h + o.kp16) + so;
+      for (int j = 0; j < m; j++) keypoints[dst + j] = orbx_keypoint{(int32_t)(k16[j] & 0xffffu), (int32_t)(k16[j] >> 16)};
+    }
     if (level_kps) std::memcpy(level_kps + dst, (const orbx_keypoint*)(h + o.lkp) + so, sizeof(orbx_keypoint) * m);
     if (orientations) std::memcpy(orientations + dst, (const float*)(h + o.angle) + so, sizeof(float) * m);
     if (responses) std::memcpy(responses + dst, (const float*)(h + o.resp) + so, sizeof(float) * m);
@@ -1728,7 +1764,8 @@ int orbx_batch_results_host(orbx_ctx* c, int previous, orbx_batch_view* v) {
   const uint8_t* h = c->h_outb[b];
   const bool compact = c->copy_compact[b];  // (those sections of the mirror were not copied: NULL in the view)
   v->counts = (const int32_t*)(h + o.counts);
-  v->keypoints = (const orbx_keypoint*)(h + o.kp);
+  v->keypoints = compact ? nullptr : (const orbx_keypoint*)(h + o.kp);
+  v->keypoints16 = (const uint32_t*)(h + o.kp16);
   v->level_kps = compact ? nullptr : (const orbx_keypoint*)(h + o.lkp);
   v->orientations = (const float*)(h + o.angle);
   v->responses = compact ? nullptr : (const float*)(h + o.resp);
@@ -1754,7 +1791,15 @@ int prefetch_block(orbx_ctx* c, bool compact) {
     return ORBX_OK;
   }
   HIPCHK(c, hipStreamWaitEvent(c->cstream, c->ev_done[b], 0));
-  HIPCHK(c, hipMemcpyAsync(c->h_outb[b], c->d_outb[b], compact ? o.compact : o.total, hipMemcpyDeviceToHost, c->cstream));
+  if (c->host_written[b]) {
+    // the describe kernel has written the compact record into the mirror itself (orbx_set_host_results): nothing
+    // to copy but, for the whole block, the other sections
+    if (!compact)
+      HIPCHK(c, hipMemcpyAsync(c->h_outb[b] + o.compact, c->d_outb[b] + o.compact, o.total - o.compact, hipMemcpyDeviceToHost,
+                               c->cstream));
+  } else {
+    HIPCHK(c, hipMemcpyAsync(c->h_outb[b], c->d_outb[b], compact ? o.compact : o.total, hipMemcpyDeviceToHost, c->cstream));
+  }
   HIPCHK(c, hipEventRecord(c->ev_copied[b], c->cstream));
   c->copy_pending[b] = true;
   c->copy_compact[b] = compact;

@@ -224,12 +224,19 @@ hipError_t orbx_launch_level_select_auto(hipStream_t s, const OrbxPlan& plan, in
                                          const float* d_gauss, int window, float k, uint32_t* d_cand,
                                          int32_t* d_ncand, float* d_cresp, orbx_keypoint* d_sel_lkp,
                                          float* d_sel_resp, int32_t* d_sel_count);
+// device-visible addresses of the compact sections of a result block's pinned host mirror (all null: not wanted)
+struct OrbxHostRecord {
+  int32_t* counts;
+  uint32_t* kp16;
+  float* angle;
+  orbx_descriptor* desc;
+};
 hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frames, const uint8_t* d_pyr,
                                 int patch_size, const int32_t* d_sel_count, const orbx_keypoint* d_sel_lkp,
                                 const float* d_sel_resp, int32_t* d_out_count, orbx_keypoint* d_out_lkp,
-                                float* d_out_resp, int32_t* d_out_level, orbx_keypoint* d_out_kp, float* d_out_angle,
-                                orbx_descriptor* d_out_desc, const uint32_t* d_feedback = nullptr,
-                                uint32_t* h_feedback = nullptr);
+                                float* d_out_resp, int32_t* d_out_level, orbx_keypoint* d_out_kp, uint32_t* d_out_kp16,
+                                float* d_out_angle, orbx_descriptor* d_out_desc, const uint32_t* d_feedback = nullptr,
+                                uint32_t* h_feedback = nullptr, const OrbxHostRecord* host_record = nullptr);
 
 // stage-level helpers on plain (single-image, arbitrary pitch) buffers
 hipError_t orbx_launch_describe_flat(hipStream_t s, const uint8_t* d_img, int w, int h, int pitch,

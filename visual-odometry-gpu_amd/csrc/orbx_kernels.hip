@@ -1255,15 +1255,19 @@ __global__ __launch_bounds__(64 * DESC_NW, DESC_OCC) void k_describe2(OrbxPlan p
                                                    float* __restrict__ out_resp,
                                                    int32_t* __restrict__ out_level,
                                                    orbx_keypoint* __restrict__ out_kp,
+                                                   uint32_t* __restrict__ out_kp16,
                                                    float* __restrict__ out_angle,
                                                    orbx_descriptor* __restrict__ out_desc,
-                                                   const uint32_t* __restrict__ feedback, uint32_t* __restrict__ feedback_host) {
+                                                   const uint32_t* __restrict__ feedback, uint32_t* __restrict__ feedback_host,
+                                                   OrbxHostRecord host) {
   constexpr int DESC_KPB = DESC_NW * DESC_KPW;
   static_assert(2 * DESC_KPB <= 64 * DESC_NW, "trig: two threads per keypoint");
   __shared__ __attribute__((aligned(16))) DescLds2 s_lds[DESC_NW];
   __shared__ int s_m[DESC_KPB][2];
   __shared__ float s_cs[DESC_KPB][2];
   __shared__ uint2 s_mw[4 * (DESC_PITCH / 4)];
+  // the workgroup's compact records {x | y << 16, angle, descriptor} on their way to the host (orbx_set_host_results)
+  __shared__ __attribute__((aligned(16))) uint32_t s_rec_kp[DESC_KPB], s_rec_angle[DESC_KPB], s_rec_desc[DESC_KPB][8];
   // grid = (frames, keypoint groups), the frame index dispatched fastest: with 8 XCDs dealt round-robin all
   // groups of a frame gather their patches through the same L2 (2.5 % faster than (groups, frames))
   const int f = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
@@ -1275,7 +1279,10 @@ __global__ __launch_bounds__(64 * DESC_NW, DESC_OCC) void k_describe2(OrbxPlan p
   const int lvl_cnt = lane < plan.nlevels ? sel_count[f * plan.nlevels + lane] : 0;
   const int lvl_end = wave_scan_incl(lvl_cnt);  // slots of levels 0..lane
   const int count = __builtin_amdgcn_readlane(lvl_end, 63);
-  if (grp == 0 && tid == 0) out_count[f] = count;
+  if (grp == 0 && tid == 0) {
+    out_count[f] = count;
+    if (host.counts) host.counts[f] = count;
+  }
   // (last kernel of a batch: the running totals of the top-rows-first pipeline's second pass go to the host's pinned
   // word pair, which the host reads without waiting when it enqueues later batches -- a copy node less per batch)
   if (feedback_host && grp == 0 && f == 0 && tid < 2) feedback_host[tid] = feedback[tid];
@@ -1404,7 +1411,10 @@ __global__ __launch_bounds__(64 * DESC_NW, DESC_OCC) void k_describe2(OrbxPlan p
     const int q = tid >> 1, want_sin = tid & 1;
     const float angle = orbx_atan2f((float)s_m[q][1], (float)s_m[q][0]);
     s_cs[q][want_sin] = orbx_sincosf_impl(angle, want_sin ^ 1);
-    if (!want_sin) out_angle[fo + slot0 + q] = angle;
+    if (!want_sin) {
+      out_angle[fo + slot0 + q] = angle;
+      s_rec_angle[q] = __float_as_uint(angle);
+    }
   }
   __syncthreads();
 
@@ -1466,12 +1476,37 @@ __global__ __launch_bounds__(64 * DESC_NW, DESC_OCC) void k_describe2(OrbxPlan p
         g.x = (int)__fmul_rn((float)jb.x, scale[j]);
         g.y = (int)__fmul_rn((float)jb.y, scale[j]);
         out_kp[fo + slot] = g;
+        // the same once more as x | y << 16 (coordinates <= 16384): the compact host record, 4 bytes less per slot
+        out_kp16[fo + slot] = (uint32_t)g.x | ((uint32_t)g.y << 16);
         u64* dd = reinterpret_cast<u64*>(out_desc + fo + slot);
         dd[0] = d[0];
         dd[1] = d[1];
         dd[2] = d[2];
         dd[3] = d[3];
+        if (host.desc) {
+          s_rec_kp[q] = (uint32_t)g.x | ((uint32_t)g.y << 16);
+          u64* sd = reinterpret_cast<u64*>(s_rec_desc[q]);
+          sd[0] = d[0];
+          sd[1] = d[1];
+          sd[2] = d[2];
+          sd[3] = d[3];
+        }
       }
+    }
+  }
+  // The compact record of the workgroup's keypoints, straight into the PINNED HOST mirror of the result block: three
+  // coalesced stores (16 x 32 B of descriptors, 16 x 4 B of packed keypoints, 16 x 4 B of angles) that travel the
+  // host link while the kernel runs -- no copy kernel afterwards, no wait between two streams (orbx_set_host_results)
+  if (host.desc) {  // kernel argument: uniform
+    __syncthreads();
+    const int nq = min(DESC_KPB, count - slot0);
+    if (tid < 2 * nq) {
+      const uint4 v = reinterpret_cast<const uint4*>(s_rec_desc[tid >> 1])[tid & 1];
+      reinterpret_cast<uint4*>(host.desc + fo + slot0)[tid] = v;
+    }
+    if (tid < nq) {
+      host.kp16[fo + slot0 + tid] = s_rec_kp[tid];
+      host.angle[fo + slot0 + tid] = __uint_as_float(s_rec_angle[tid]);
     }
   }
 }
@@ -1695,24 +1730,26 @@ hipError_t orbx_launch_level_select_auto(hipStream_t s, const OrbxPlan& plan, in
 hipError_t orbx_launch_describe(hipStream_t s, const OrbxPlan& plan, int n_frames, const uint8_t* d_pyr,
                                 int patch_size, const int32_t* d_sel_count, const orbx_keypoint* d_sel_lkp,
                                 const float* d_sel_resp, int32_t* d_out_count, orbx_keypoint* d_out_lkp,
-                                float* d_out_resp, int32_t* d_out_level, orbx_keypoint* d_out_kp, float* d_out_angle,
-                                orbx_descriptor* d_out_desc, const uint32_t* d_feedback, uint32_t* h_feedback) {
+                                float* d_out_resp, int32_t* d_out_level, orbx_keypoint* d_out_kp, uint32_t* d_out_kp16,
+                                float* d_out_angle, orbx_descriptor* d_out_desc, const uint32_t* d_feedback,
+                                uint32_t* h_feedback, const OrbxHostRecord* host_record) {
+  const OrbxHostRecord host = host_record ? *host_record : OrbxHostRecord{};
   if (plan.out_cap <= 0) return hipSuccess;
   // few keypoints in flight (single frames, small batches): one keypoint per wave, four times the
   // workgroups, a quarter of the serial work per wave; else four per wave
   if ((long long)plan.out_cap * n_frames <= 8192) {
     dim3 grid(n_frames, (plan.out_cap + 3) / 4);
     hipLaunchKernelGGL((k_describe2<1, 4, 1>), grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
-                       d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc, d_feedback,
-                       h_feedback);
+                       d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_kp16, d_out_angle, d_out_desc, d_feedback,
+                       h_feedback, host);
   } else {
     // Four waves of four keypoints, registers capped for 7 waves per SIMD (5.1 KB of LDS per wave: 7 workgroups
     // per CU).  Measured per 256 frames: 8-wave workgroups at 6 waves per SIMD (the trig -- two threads per
     // keypoint -- fills a wave: -1.8 % instructions) 203 us, 7-wave workgroups 221 us, this 197 us.
     dim3 grid(n_frames, (plan.out_cap + 15) / 16);
     hipLaunchKernelGGL((k_describe2<4, 4, 7>), grid, dim3(256), 0, s, plan, d_pyr, patch_size, d_sel_count, d_sel_lkp,
-                       d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_angle, d_out_desc, d_feedback,
-                       h_feedback);
+                       d_sel_resp, d_out_count, d_out_lkp, d_out_resp, d_out_level, d_out_kp, d_out_kp16, d_out_angle, d_out_desc, d_feedback,
+                       h_feedback, host);
   }
   return ORBX_LAUNCH_CHECK();
 }

@@ -30,7 +30,7 @@ EXPORTS = [
     "orbx_wait", "orbx_batch_results_device", "orbx_batch_results_host", "orbx_batch_fetch", "orbx_batch_prefetch", "orbx_batch_prefetch_compact",
     "orbx_batch_fetch_previous", "orbx_enable_stage_timing",
     "orbx_last_stage_times", "orbx_stage_times_history", "orbx_bench_stage", "orbx_set_fast_early_exit",
-    "orbx_set_fused_pyramid_blur", "orbx_set_top_rows_first", "orbx_set_pipelined_batches", "orbx_fast_tile_counts", "orbx_pyramid_pixel_counts", "orbx_lk_track", "orbx_lk_pyramid_levels", "orbx_fast_score", "orbx_nms", "orbx_fast",
+    "orbx_set_fused_pyramid_blur", "orbx_set_top_rows_first", "orbx_set_pipelined_batches", "orbx_set_host_results", "orbx_fast_tile_counts", "orbx_pyramid_pixel_counts", "orbx_lk_track", "orbx_lk_pyramid_levels", "orbx_fast_score", "orbx_nms", "orbx_fast",
     "orbx_orientations", "orbx_brief", "orbx_harris", "orbx_blur5_sep", "orbx_blur5_273", "orbx_conv2d",
     "orbx_gaussian_blur_conv", "orbx_gaussian_kernel", "orbx_sobel", "orbx_build_pyramid_level",
     "orbx_select_top", "orbx_knn2", "orbx_match_ratio", "orbx_batch_match_consecutive", "orbx_batch_match_fetch",
@@ -52,6 +52,7 @@ class BatchView(C.Structure):
         ("counts", C.c_void_p), ("keypoints", C.c_void_p), ("level_kps", C.c_void_p),
         ("orientations", C.c_void_p), ("responses", C.c_void_p), ("levels", C.c_void_p),
         ("descriptors", C.c_void_p), ("slot_capacity", C.c_int32), ("n", C.c_int32),
+        ("keypoints16", C.c_void_p),
     ]
 
 
@@ -252,14 +253,17 @@ class Context:
             size = int(np.prod(shape)) * np.dtype(dtype).itemsize
             return np.frombuffer((C.c_char * size).from_address(ptr), dtype=dtype).reshape(shape)
 
+        # kps16: the level-0 coordinates as (x, y) uint16 pairs (x | y << 16, little endian); the only keypoint
+        # section of a compact copy
         return dict(counts=arr(v.counts, np.int32, (n,)), kps=arr(v.keypoints, np.int32, (n, cap, 2)),
+                    kps16=arr(v.keypoints16, np.uint16, (n, cap, 2)),
                     kps_level=arr(v.level_kps, np.int32, (n, cap, 2)), angles=arr(v.orientations, np.float32, (n, cap)),
                     responses=arr(v.responses, np.float32, (n, cap)), levels=arr(v.levels, np.int32, (n, cap)),
                     desc=arr(v.descriptors, np.uint8, (n, cap, 32)))
 
     def batch_prefetch(self, compact=False):
         """Start the asynchronous D2H copy of the last batch's result block (overlaps the next batch); compact: only
-        counts, keypoints, orientations and descriptors (orbx_batch_prefetch_compact)."""
+        counts, packed keypoints (kps16), orientations and descriptors (orbx_batch_prefetch_compact)."""
         if compact:
             self._chk(self._lib.orbx_batch_prefetch_compact(self._h))
         else:
@@ -290,6 +294,10 @@ class Context:
 
     def set_fused_pyramid_blur(self, on=True):
         self._chk(self._lib.orbx_set_fused_pyramid_blur(self._h, 1 if on else 0))
+
+    def set_host_results(self, on=True):
+        """The describe kernel also writes the compact record into the pinned host mirror (orbx_set_host_results)."""
+        self._chk(self._lib.orbx_set_host_results(self._h, 1 if on else 0))
 
     def set_pipelined_batches(self, on=True):
         """Consecutive batch_device calls alternate between two lanes (own stream, own pools) and overlap."""
