@@ -87,6 +87,10 @@ def main():
                 c.set_fast_early_exit(bool(rng.integers(0, 2)))
                 c.set_fused_pyramid_blur(bool(rng.integers(0, 2)))
                 hostres = bool(rng.integers(0, 2))  # the describe kernel also writes the compact record to the host
+                if os.environ.get("FUZZ_HOSTRES"):
+                    hostres = os.environ["FUZZ_HOSTRES"] == "1"
+                if only is not None and int(only) == it:
+                    print("replay: host results", hostres, "batch", B, "big", big, flush=True)
                 c.set_host_results(hostres)
                 if big and rng.random() < 0.5:
                     # device-resident batches through the two lanes of the pipelined mode, back to back: the

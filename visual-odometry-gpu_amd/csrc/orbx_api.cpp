@@ -593,8 +593,12 @@ int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string
   }
   plan->frame_bytes = (int32_t)img_off;
   plan->mask_words = (int32_t)mask_off;
-  plan->cand_total = cand_off;
-  plan->out_cap = out_cap;
+  // (the selection output lives in the candidate pools, at the result blocks' stride: in the row-major mode, where a
+  // level's cap is its quota, the rounded-up slot count below is the larger of the two)
+  plan->cand_total = std::max(cand_off, (out_cap + 15) & ~15);
+  // slots per frame of the result blocks: the sum of the quotas, rounded up to 16 -- a describe workgroup's 16 slots
+  // are then whole 64-byte lines of every section (fewer, full-line writes when the record goes to the host mirror)
+  plan->out_cap = (out_cap + 15) & ~15;
   return ORBX_OK;
 }
 
