@@ -179,9 +179,10 @@ int orbx_batch_prefetch_compact(orbx_ctx* ctx);
 /* Host results without a copy (default off): with enable = 1 the kernel that finishes a batch (orientation + BRIEF)
  * writes the compact record -- counts | keypoints16 | orientations | descriptors -- of every keypoint into the block's
  * PINNED HOST mirror as well, in coalesced stores that travel the host link while the kernel runs.
- * orbx_batch_prefetch_compact then only marks the block (nothing is copied, no copy kernel competes with the next
- * batch), orbx_batch_prefetch copies the other sections, and the host views / fetches deliver the same bytes as
- * before.  The device-side result block is written as always.  (The reference copies every stage's results back
+ * The block then counts as compact-copied from the moment its batch is enqueued: orbx_batch_prefetch_compact has
+ * nothing to do (nothing is copied, no copy kernel competes with the next batch, the copy stream is not involved),
+ * orbx_batch_prefetch copies the other sections, and the host views / fetches wait for the batch's end and deliver
+ * the same bytes as before (orbx_batch_results_host without a preceding orbx_batch_prefetch: the compact view).  The device-side result block is written as always.  (The reference copies every stage's results back
  * with a blocking cudaMemcpy: src/cuda/Fast.cu:238-239, src/cuda/Brief.cu:131.)  bench.py: fps_with_d2h. */
 int orbx_set_host_results(orbx_ctx* ctx, int enable);
 /* Zero-copy host view of a result block: pointers into the context's PINNED mirror of the last batch

@@ -1130,6 +1130,13 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   c->copy_pending[blk] = false;
   c->host_written[blk] = c->host_results && c->plan.out_cap > 0;
   HIPCHK(c, hipEventRecord(c->ev_done[blk], s));
+  if (c->host_written[blk]) {
+    // orbx_set_host_results: the compact record is in the pinned mirror when the batch ends -- the block counts as
+    // compact-copied from the start (the copy stream is not involved; orbx_batch_prefetch_compact has nothing to do)
+    HIPCHK(c, hipEventRecord(c->ev_copied[blk], s));
+    c->copy_pending[blk] = true;
+    c->copy_compact[blk] = true;
+  }
   HIPCHK(c, hipEventRecord(c->ev_pool[lane], s));
   c->pool_stream[lane] = s;
   c->blk_stream[blk] = s;
@@ -1788,22 +1795,17 @@ int prefetch_block(orbx_ctx* c, bool compact) {
   if (c->copy_pending[b]) {
     if (compact || !c->copy_compact[b]) return ORBX_OK;
     // a compact copy is on its way and the whole block is wanted after all: the other sections follow it
+    HIPCHK(c, hipStreamWaitEvent(c->cstream, c->ev_done[b], 0));  // (host results: the compact part never was on this stream)
     HIPCHK(c, hipMemcpyAsync(c->h_outb[b] + o.compact, c->d_outb[b] + o.compact, o.total - o.compact, hipMemcpyDeviceToHost,
                              c->cstream));
     HIPCHK(c, hipEventRecord(c->ev_copied[b], c->cstream));
     c->copy_compact[b] = false;
     return ORBX_OK;
   }
+  // (a block the describe kernel has written its compact record into -- orbx_set_host_results -- never gets here:
+  // it is compact-pending from the moment the batch is enqueued)
   HIPCHK(c, hipStreamWaitEvent(c->cstream, c->ev_done[b], 0));
-  if (c->host_written[b]) {
-    // the describe kernel has written the compact record into the mirror itself (orbx_set_host_results): nothing
-    // to copy but, for the whole block, the other sections
-    if (!compact)
-      HIPCHK(c, hipMemcpyAsync(c->h_outb[b] + o.compact, c->d_outb[b] + o.compact, o.total - o.compact, hipMemcpyDeviceToHost,
-                               c->cstream));
-  } else {
-    HIPCHK(c, hipMemcpyAsync(c->h_outb[b], c->d_outb[b], compact ? o.compact : o.total, hipMemcpyDeviceToHost, c->cstream));
-  }
+  HIPCHK(c, hipMemcpyAsync(c->h_outb[b], c->d_outb[b], compact ? o.compact : o.total, hipMemcpyDeviceToHost, c->cstream));
   HIPCHK(c, hipEventRecord(c->ev_copied[b], c->cstream));
   c->copy_pending[b] = true;
   c->copy_compact[b] = compact;
