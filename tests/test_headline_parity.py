@@ -204,6 +204,42 @@ def test_host_results_written_by_the_describe_kernel(pkg, batches256, oracle256,
         compare(c.batch_host_view(), oracle256[1][:n], full=False)
 
 
+def test_adaptive_first_pass_changes_the_tile_rows_not_the_results(pkg, batches256, oracle256):
+    """The adaptive mode of the top-rows-first pipeline learns in which row the levels' caps fill and shortens the FAST
+    tile rows so that the first pass ends just below (orbx_api.cpp, adapt_tile_rows): after a few batches the tile
+    table of a frame has more, shorter tile rows.  Every batch before, during and after the change equals the oracle;
+    with the early exit switched off the default tile rows come back, and again with it on the learned ones."""
+    import torch
+
+    n = 128
+    d = [torch.from_numpy(batches256[k][:n]).cuda() for k in range(2)]
+    torch.cuda.synchronize()
+    p = pkg.default_params("gpu", max_width=W, max_height=H, max_batch=n, **PK)
+    with pkg.Context(p) as c:
+        cap = c.plan(W, H)["out_capacity"]
+        totals = []
+        for i in range(10):
+            c.batch_device(d[i & 1].data_ptr(), n, W, H)
+            compare(c.batch_fetch(0, n, cap), oracle256[i & 1][:n])
+            totals.append(c.fast_tile_counts()[1])
+        assert totals[0] == 272 * n  # the default table (test_fast_tile_counts)
+        assert totals[-1] > totals[0], totals  # shorter tile rows: more tiles
+        learned = totals[-1]
+        c.set_pipelined_batches(True)
+        for i in range(6):
+            c.batch_device(d[i & 1].data_ptr(), n, W, H)
+        compare(c.batch_fetch(0, n, cap), oracle256[1][:n])
+        c.set_pipelined_batches(False)
+        c.set_fast_early_exit(False)  # every tile works: the default rows (smaller halo share)
+        c.batch_device(d[0].data_ptr(), n, W, H)
+        compare(c.batch_fetch(0, n, cap), oracle256[0][:n])
+        assert c.fast_tile_counts()[1] == totals[0]
+        c.set_fast_early_exit(True)
+        c.batch_device(d[1].data_ptr(), n, W, H)
+        compare(c.batch_fetch(0, n, cap), oracle256[1][:n])
+        assert c.fast_tile_counts()[1] == learned
+
+
 def test_config4_1080p_as_a_batch(pkg):
     """BASELINE.json configs[4] through the batched device path: 8 stream-B 1920x1080 frames, 12 levels, 4000 features,
     Harris + NMS (level caps > 512: the three-kernel selection; caps not reached in the top rows: the adaptive mode

@@ -208,6 +208,12 @@ struct orbx_ctx {
   uint32_t* d_feedback = nullptr;
   volatile uint32_t* h_feedback = nullptr;
   uint32_t feedback_seen[2] = {0, 0};
+  // adaptive first pass (adapt_tile_rows): rows each level needed to fill its cap -- maximum of the current and of
+  // the previous observation window --, the tile-row heights chosen from them (0: the default), bookkeeping
+  uint32_t need_cur[ORBX_MAX_LEVELS] = {}, need_prev[ORBX_MAX_LEVELS] = {};
+  int tile_h_pref[ORBX_MAX_LEVELS] = {};
+  int need_batches = 0, need_window = 2, retiles = 0, learn_w = 0, learn_h = 0;
+  bool prefs_applied = false;  // the current tile tables were built with tile_h_pref
   // ring of event sets: one per timed batched call, so that several calls can be
   // in flight before their stage times are read (no host sync between steps)
   // (slots ORBX_NUM_STAGE_TIMES + 1, + 2: the boundaries inside the top-rows-first pipeline)
@@ -312,7 +318,8 @@ void make_tilemap(const OrbxPlan& plan, int tw, int th, bool use_pitch, OrbxTile
 // levels that have a tile row b are always a prefix of the level list)
 // strips: the units of the streaming kernel of the whole path (orbx_fast4.hip: a wave per 64-dword strip and tile
 // row) instead of the 128-pixel tiles of the LDS tile kernel (stage operators)
-int make_bandmap(const OrbxPlan& plan, int nms_radius, OrbxBandMap* bm, std::string* why, bool strips = false) {
+int make_bandmap(const OrbxPlan& plan, int nms_radius, OrbxBandMap* bm, std::string* why, bool strips = false,
+                 const int* pref_h = nullptr) {
   std::memset(bm, 0, sizeof(*bm));
   const int tw = ORBX_FAST3_TW, th = orbx_fast3_tile_h(nms_radius);
   int nb = 0;
@@ -320,6 +327,17 @@ int make_bandmap(const OrbxPlan& plan, int nms_radius, OrbxBandMap* bm, std::str
     bm->tiles_x[l] = strips ? orbx_fast4_strips(plan.L[l].w, nms_radius) : (plan.L[l].w + tw - 1) / tw;
     bm->tiles_y[l] = (plan.L[l].h + th - 1) / th;
     bm->tile_h[l] = (plan.L[l].h + bm->tiles_y[l] - 1) / bm->tiles_y[l];  // balanced tile rows
+    // pref_h[l] > 0: SHORTER tile rows for this level (the adaptive first pass of the top-rows-first pipeline:
+    // adapt_tile_rows) -- never more tile rows than ORBX_MAX_BANDS or than the level above has (band-major order)
+    if (pref_h && pref_h[l] > 0 && pref_h[l] < bm->tile_h[l]) {
+      int hh = std::max(pref_h[l], ORBX_MIN_TILE_H);
+      const int most = l > 0 ? std::min(bm->tiles_y[l - 1], ORBX_MAX_BANDS) : ORBX_MAX_BANDS;
+      while ((plan.L[l].h + hh - 1) / hh > most) hh++;
+      if (hh < bm->tile_h[l]) {
+        bm->tile_h[l] = hh;
+        bm->tiles_y[l] = (plan.L[l].h + hh - 1) / hh;
+      }
+    }
     bm->xprefix[l + 1] = bm->xprefix[l] + bm->tiles_x[l];
     if (l > 0 && bm->tiles_y[l] > bm->tiles_y[l - 1]) {
       *why = "pyramid levels must not grow with the level index";
@@ -741,6 +759,13 @@ hipError_t lanes_sync(orbx_ctx* c) {
   return hipSuccess;
 }
 
+bool fused_pyrblur(const orbx_ctx* c);
+bool fast_early_on(const orbx_ctx* c);
+int top_rows_env();
+bool tile_prefs_apply(const orbx_ctx* c) {
+  return c->top_mode == 2 && top_rows_env() > 0 && fast_early_on(c) && fused_pyrblur(c);
+}
+
 int set_plan(orbx_ctx* c, int w, int h) {
   if (w == c->plan_w && h == c->plan_h) return ORBX_OK;
   if (w < 8 || h < 8 || w > c->p.max_width || h > c->p.max_height)
@@ -768,7 +793,12 @@ int set_plan(orbx_ctx* c, int w, int h) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   make_tilemap(plan, ORBX_BLUR_TW, ORBX_BLUR_TH, true, &c->tm_blur);
-  if ((st = make_bandmap(plan, c->p.nms_window / 2, &c->bm_fast, &why, c->fast_impl == 4)) != ORBX_OK) return fail(c, st, why);
+  // (the adaptive first pass's shorter tile rows only where the top-rows-first pipeline can run at all: with the
+  // early exit or the fused kernel switched off every tile works, and the default rows have the smaller halo share)
+  c->prefs_applied = tile_prefs_apply(c);
+  if ((st = make_bandmap(plan, c->p.nms_window / 2, &c->bm_fast, &why, c->fast_impl == 4,
+                         c->prefs_applied ? c->tile_h_pref : nullptr)) != ORBX_OK)
+    return fail(c, st, why);
   {
     std::vector<OrbxTileDesc> t;
     blur_tiles_for_impl(c->blur_impl, plan, &t);
@@ -923,6 +953,57 @@ void top_rows_update(orbx_ctx* c) {
   }
 }
 
+// Adaptive first pass.  The top-rows-first pipeline produces and searches the first ORBX_TOP_ROWS FAST tile rows of
+// every level before anything else; with the default tile rows (<= 47 rows, balanced) that is ~90 rows per level,
+// while a level's cap is typically full after 40-75 rows on the benchmark stream -- and everything a first-pass tile
+// row holds beyond that row is work nobody reads.  The selection kernel reports, per level, the row in which the
+// cap filled (maximum over the frames of a batch; the whole level if it never did); from the maximum over the last
+// two observation windows, plus a margin, this picks SHORTER tile rows for the level, so that the first pass ends
+// just below that row.  Only the partition of the work changes, never a result; a stream whose caps fill lower
+// gets taller tile rows back (at most the default), and a frame whose cap is not full after the first pass is
+// finished by the second one as always.  Returns true if the tile tables must be rebuilt (the caller forces
+// set_plan, which waits for the batches in flight: it happens a few times per stream, not per batch).
+bool adapt_tile_rows(orbx_ctx* c) {
+  if (!tile_prefs_apply(c) || !c->h_feedback || c->plan_w <= 0) return false;
+  const int top = top_rows_env(), nl = c->plan.nlevels;
+  bool any = false;
+  for (int l = 0; l < nl; l++) {
+    const uint32_t v = c->h_feedback[2 + l];  // (whatever has arrived; a stale or torn word only misleads the heuristic)
+    if (v) {
+      c->need_cur[l] = std::max(c->need_cur[l], std::min<uint32_t>(v, (uint32_t)c->plan.L[l].h));
+      any = true;
+    }
+  }
+  if (!any || ++c->need_batches < c->need_window) return false;
+  // end of an observation window (2, 4, 8, 16, then every 32 batches)
+  c->need_batches = 0;
+  c->need_window = std::min(2 * c->need_window, 32);
+  bool change = false, grow = false;
+  int want[ORBX_MAX_LEVELS] = {};
+  for (int l = 0; l < nl; l++) {
+    const uint32_t need = std::max(c->need_cur[l], c->need_prev[l]);
+    c->need_prev[l] = c->need_cur[l];
+    c->need_cur[l] = 0;
+    if (need == 0) {
+      want[l] = c->tile_h_pref[l];
+      continue;
+    }
+    const int rows = (int)need + std::max(4, (int)need / 10);  // margin: the next frames' caps may fill a little lower
+    int hh = (rows + top - 1) / top;
+    const int cur = c->bm_fast.tile_h[l];
+    if (hh >= orbx_fast3_tile_h(c->p.nms_window / 2) || c->plan.L[l].h <= top * hh) hh = 0;  // the default rows do
+    want[l] = hh;
+    const int eff = hh ? hh : orbx_fast3_tile_h(c->p.nms_window / 2);
+    if (eff > cur) grow = true;                 // the first pass is too short for this stream: always follow
+    else if (eff + 2 < cur) change = true;      // shrink only for a gain of three rows or more
+  }
+  if (!grow && !change) return false;
+  if (!grow && c->retiles >= 4 && c->need_window < 32) return false;  // (settle first)
+  for (int l = 0; l < nl; l++) c->tile_h_pref[l] = want[l];
+  c->retiles++;
+  return true;
+}
+
 // the launches of the whole path for n frames already on the device (the plan is set)
 int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, size_t frame_stride, hipStream_t s) {
   const OrbxPlan& P = c->plan;
@@ -969,7 +1050,7 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
     } else {
       const int first_tiles = c->bm_fast.band_begin[top_rows_env()];
       HIPCHK(c, orbx_launch_pyrblur(s, c->d_tiles_pyrblur_top, c->pyrblur_top_count, P.frame_bytes, P.w0, P.h0, n, d_frames,
-                                    row_stride, frame_stride, c->d_taps, c->d_pyr_blur, pyr_group_env(), nullptr, nullptr, nullptr,
+                                    row_stride, frame_stride, c->d_taps, c->d_pyr_blur, pyr_group_env(), nullptr, c->d_feedback, nullptr,
                                     c->d_row_stat));
       HIPCHK(c, mark(ORBX_NUM_STAGE_TIMES + 1, true));
       HIPCHK(c, launch_fast_tiles(c, s, 0, first_tiles, n, fp, c->d_row_stat));
@@ -1005,7 +1086,7 @@ int enqueue_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int row_stride, s
   }();
   HIPCHK(c, orbx_launch_level_select_auto(s, P, n, c->p.select_mode, spread, c->d_mask, final_pyr(c), c->d_gauss,
                                           c->p.harris_window, c->p.harris_k, c->d_lcand, c->d_lcount, c->d_lresp,
-                                          c->d_cand, c->d_resp, c->d_cand_count));
+                                          c->d_cand, c->d_resp, c->d_cand_count, two_pass ? c->d_feedback + 2 : nullptr));
   HIPCHK(c, mark(6, false));
   if (P.out_cap <= 0)  // nfeatures too small for any quota: no describe launch, so the counts are zeroed here
     HIPCHK(c, hipMemsetAsync(c->d_out + o.counts, 0, sizeof(int32_t) * (size_t)n, s));
@@ -1042,6 +1123,22 @@ int run_batch(orbx_ctx* c, const uint8_t* d_frames, int n, int w, int h, int row
   // Pipelined mode: a device-resident batch on the context's stream goes to the lane of its result block -- own
   // pools, own stream, so nothing of the other lane's batch in flight is touched.  (The plan's tables are shared:
   // set_plan waits for both lanes before it changes them.)
+  // adaptive first pass (adapt_tile_rows): what was learned belongs to one frame size; new tile-row heights make
+  // set_plan below rebuild the tables (it waits for the batches in flight; this batch then runs unpipelined)
+  if (w != c->learn_w || h != c->learn_h) {
+    c->learn_w = w;
+    c->learn_h = h;
+    for (int l = 0; l < ORBX_MAX_LEVELS; l++) c->need_cur[l] = c->need_prev[l] = 0, c->tile_h_pref[l] = 0;
+    for (int i = 2; i < ORBX_FEEDBACK_WORDS; i++) c->h_feedback[i] = 0;
+    c->need_batches = 0;
+    c->need_window = 2;
+    c->retiles = 0;
+  } else if (w == c->plan_w && h == c->plan_h) {
+    bool any_pref = false;
+    for (int l = 0; l < ORBX_MAX_LEVELS; l++) any_pref |= c->tile_h_pref[l] != 0;
+    // (a switch that takes the top-rows-first pipeline away, or brings it back, since the tables were built)
+    if (adapt_tile_rows(c) || (any_pref && tile_prefs_apply(c) != c->prefs_applied)) c->plan_w = 0;
+  }
   const bool lanes = may_pipeline && c->pipelined && s == c->stream && w == c->plan_w && h == c->plan_h;
   const int lane = lanes ? c->next_lane : 0;
   if (lanes) {
@@ -1370,13 +1467,15 @@ int orbx_create(const orbx_params* p, orbx_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_pyr_blur, B * (size_t)M.frame_bytes + 256));
   CREATE_CHK(hipMalloc((void**)&c->d_mask, B * (size_t)M.mask_words * 8 + 256));
   CREATE_CHK(hipMalloc((void**)&c->d_row_stat, B * ORBX_FAST_STAT_WORDS * 8));
-  CREATE_CHK(hipMalloc((void**)&c->d_feedback, 8));
-  CREATE_CHK(hipMemset(c->d_feedback, 0, 8));
-  CREATE_CHK(hipHostMalloc((void**)&c->h_feedback, 8, hipHostMallocDefault));
-  c->h_feedback[0] = c->h_feedback[1] = 0;
+  CREATE_CHK(hipMalloc((void**)&c->d_feedback, ORBX_FEEDBACK_WORDS * 4));
+  CREATE_CHK(hipMemset(c->d_feedback, 0, ORBX_FEEDBACK_WORDS * 4));
+  CREATE_CHK(hipHostMalloc((void**)&c->h_feedback, ORBX_FEEDBACK_WORDS * 4, hipHostMallocDefault));
+  for (int i = 0; i < ORBX_FEEDBACK_WORDS; i++) c->h_feedback[i] = 0;
   {
-    OrbxBandMap bmm;
-    if ((st = make_bandmap(M, p->nms_window / 2, &bmm, &why, c->fast_impl == 4)) != ORBX_OK) {
+    OrbxBandMap bmm;  // (sized for the shortest tile rows the adaptive first pass may choose)
+    int min_pref[ORBX_MAX_LEVELS];
+    for (int l = 0; l < ORBX_MAX_LEVELS; l++) min_pref[l] = ORBX_MIN_TILE_H;
+    if ((st = make_bandmap(M, p->nms_window / 2, &bmm, &why, c->fast_impl == 4, min_pref)) != ORBX_OK) {
       orbx_destroy(c);
       return fail(nullptr, st, why);
     }

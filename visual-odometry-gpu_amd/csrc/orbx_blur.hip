@@ -642,6 +642,8 @@ __global__ __launch_bounds__(256, 8) void k_pyrblur(const OrbxTileDesc* __restri
   // statistics (the FAST launch that fills them comes after this kernel): a memset node less per batch
   if (zero_stat && wg == 0)
     for (int i = threadIdx.x; i < ORBX_FAST_STAT_WORDS; i += 256) zero_stat[(size_t)f * ORBX_FAST_STAT_WORDS + i] = 0ull;
+  // ... and the first workgroup of the batch the rows-needed words the selection kernel will fill (a maximum per batch)
+  if (zero_stat && feedback && wg == 0 && f == 0 && threadIdx.x < ORBX_MAX_LEVELS) feedback[2 + threadIdx.x] = 0u;
   const int ti = wg * 4 + wave;
   if (ti >= n_tiles) return;  // whole wave
   const OrbxTileDesc d = tiles[ti];

@@ -59,6 +59,12 @@ struct OrbxTileMap {
 // FAST early-exit state per frame (u64 words): tile-row statistics [level][band], then one
 // "dead from band" word per level
 #define ORBX_FAST_STAT_WORDS (ORBX_MAX_LEVELS * ORBX_MAX_BANDS + ORBX_MAX_LEVELS)
+// feedback words of the top-rows-first pipeline (device, mirrored in pinned host memory by the batch's last kernel):
+// [0] levels skipped, [1] levels produced (running totals), [2 + l] rows level l needed to fill its cap (maximum
+// over the frames of the last batch; 0: not reported)
+#define ORBX_FEEDBACK_WORDS (2 + ORBX_MAX_LEVELS)
+// smallest FAST tile-row height the adaptive first pass may choose (orbx_api.cpp, adapt_tile_rows)
+#define ORBX_MIN_TILE_H 16
 struct OrbxBandMap {
   int32_t nbands;
   int32_t band_begin[ORBX_MAX_BANDS + 1];  // tiles PER FRAME before band b (+ total)
@@ -216,14 +222,14 @@ hipError_t orbx_launch_harris_flat(hipStream_t s, const uint8_t* d_img, int w, i
 hipError_t orbx_launch_level_select(hipStream_t s, const OrbxPlan& plan, int n_frames, int mode,
                                     const unsigned long long* d_mask, const uint8_t* d_pyr, const float* d_gauss,
                                     int window, float k, orbx_keypoint* d_sel_lkp, float* d_sel_resp,
-                                    int32_t* d_sel_count);
+                                    int32_t* d_sel_count, uint32_t* d_need = nullptr);
 // fused kernel or the three spread kernels, chosen by shape (force: 0 fused, 1 spread, -1 auto);
 // d_cand / d_cresp: cand_total slots per frame, d_ncand: nlevels per frame (spread path only)
 hipError_t orbx_launch_level_select_auto(hipStream_t s, const OrbxPlan& plan, int n_frames, int mode, int force,
                                          const unsigned long long* d_mask, const uint8_t* d_pyr,
                                          const float* d_gauss, int window, float k, uint32_t* d_cand,
                                          int32_t* d_ncand, float* d_cresp, orbx_keypoint* d_sel_lkp,
-                                         float* d_sel_resp, int32_t* d_sel_count);
+                                         float* d_sel_resp, int32_t* d_sel_count, uint32_t* d_need = nullptr);
 // device-visible addresses of the compact sections of a result block's pinned host mirror (all null: not wanted)
 struct OrbxHostRecord {
   int32_t* counts;

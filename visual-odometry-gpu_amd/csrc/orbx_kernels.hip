@@ -655,7 +655,8 @@ __global__ __launch_bounds__(LVL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
                                                               const float* __restrict__ gauss, int K, float kk,
                                                               orbx_keypoint* __restrict__ sel_lkp,
                                                               float* __restrict__ sel_resp,
-                                                              int32_t* __restrict__ sel_count) {
+                                                              int32_t* __restrict__ sel_count,
+                                                              uint32_t* __restrict__ need) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ int s_wsum[4][LVL_THREADS / 64];
   // grid = (frames, levels), the frame index dispatched fastest.  Workgroups are dealt round-robin over
@@ -718,6 +719,10 @@ __global__ __launch_bounds__(LVL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   const int keep = n < L.quota ? n : L.quota;
   const size_t so = (size_t)f * plan.out_cap + L.out_off;
   if (tid == 0) sel_count[f * plan.nlevels + l] = keep;
+  // How many rows of the level did it take to fill the cap (all of them if it never filled)?  The maximum over the
+  // batch's frames goes to the host, which sizes the first pass of the top-rows-first pipeline by it (orbx_api.cpp,
+  // adapt_tile_rows): a heuristic's input, results never depend on it.
+  if (need && tid == 0 && cap > 0) atomicMax(&need[l], base >= cap ? (s_kp[cap - 1] >> 16) + 1u : (uint32_t)L.h);
 
   if (mode == ORBX_SELECT_ROWMAJOR) {
     for (int i = tid; i < keep; i += LVL_THREADS) {
@@ -1285,7 +1290,8 @@ __global__ __launch_bounds__(64 * DESC_NW, DESC_OCC) void k_describe2(OrbxPlan p
   }
   // (last kernel of a batch: the running totals of the top-rows-first pipeline's second pass go to the host's pinned
   // word pair, which the host reads without waiting when it enqueues later batches -- a copy node less per batch)
-  if (feedback_host && grp == 0 && f == 0 && tid < 2) feedback_host[tid] = feedback[tid];
+  // (+ the rows-needed word of every level: k_level_select above)
+  if (feedback_host && grp == 0 && f == 0 && tid < ORBX_FEEDBACK_WORDS) feedback_host[tid] = feedback[tid];
   const int slot0 = grp * DESC_KPB;
   if (slot0 >= count) return;  // whole workgroup
   DescLds2& lds = s_lds[wave];
@@ -1694,13 +1700,13 @@ hipError_t orbx_launch_compact(hipStream_t s, const OrbxPlan& plan, int n_frames
 hipError_t orbx_launch_level_select(hipStream_t s, const OrbxPlan& plan, int n_frames, int mode,
                                     const unsigned long long* d_mask, const uint8_t* d_pyr, const float* d_gauss,
                                     int window, float k, orbx_keypoint* d_sel_lkp, float* d_sel_resp,
-                                    int32_t* d_sel_count) {
+                                    int32_t* d_sel_count, uint32_t* d_need) {
   int maxcap = 2;
   for (int l = 0; l < plan.nlevels; l++) maxcap = plan.L[l].cap > maxcap ? plan.L[l].cap : maxcap;
   const size_t lds = (size_t)((maxcap + 1) & ~1) * 16;
   dim3 grid(n_frames, plan.nlevels);
   hipLaunchKernelGGL(k_level_select, grid, dim3(LVL_THREADS), lds, s, plan, mode, d_mask, d_pyr, d_gauss, window, k,
-                     d_sel_lkp, d_sel_resp, d_sel_count);
+                     d_sel_lkp, d_sel_resp, d_sel_count, d_need);
   return ORBX_LAUNCH_CHECK();
 }
 
@@ -1710,14 +1716,14 @@ hipError_t orbx_launch_level_select_auto(hipStream_t s, const OrbxPlan& plan, in
                                          const unsigned long long* d_mask, const uint8_t* d_pyr,
                                          const float* d_gauss, int window, float k, uint32_t* d_cand,
                                          int32_t* d_ncand, float* d_cresp, orbx_keypoint* d_sel_lkp,
-                                         float* d_sel_resp, int32_t* d_sel_count) {
+                                         float* d_sel_resp, int32_t* d_sel_count, uint32_t* d_need) {
   int maxcap = 2;
   for (int l = 0; l < plan.nlevels; l++) maxcap = plan.L[l].cap > maxcap ? plan.L[l].cap : maxcap;
   const bool spread = mode == ORBX_SELECT_HARRIS &&
                       (force >= 0 ? force != 0 : maxcap > LVL_THREADS);  // more than one candidate per thread
   if (!spread)
     return orbx_launch_level_select(s, plan, n_frames, mode, d_mask, d_pyr, d_gauss, window, k, d_sel_lkp,
-                                    d_sel_resp, d_sel_count);
+                                    d_sel_resp, d_sel_count, d_need);  // (the spread kernels do not report)
   hipLaunchKernelGGL(k_lvl_compact, dim3(plan.nlevels, n_frames), dim3(256), 0, s, plan, d_mask, d_cand, d_ncand);
   hipLaunchKernelGGL(k_lvl_harris, dim3((maxcap + 255) / 256, plan.nlevels, n_frames), dim3(256), 0, s, plan, d_pyr,
                      d_gauss, window, k, d_cand, d_ncand, d_cresp);
