@@ -111,8 +111,12 @@ def main():
                     r = c.batch_fetch(0, B, cap)
                     c.set_pipelined_batches(False)
                 else:
-                    if big:  # another batch first: rows a skipped strip leaves in the pool must never be read
-                        c.batch_host(np.ascontiguousarray(imgs[::-1]))
+                    if big:  # other batches first: rows a skipped strip leaves in the pool must never be read, and after
+                        # two of them the adaptive first pass re-partitions the FAST tile rows (adapt_tile_rows)
+                        rev = np.ascontiguousarray(imgs[::-1])
+                        for k in range(int(rng.integers(1, 5))):
+                            c.batch_host(rev if k % 2 == 0 else imgs)
+                            c.wait()
                     c.batch_host(imgs)
                     hv = host_record(c) if hostres else None
                     r = c.batch_fetch(0, B, cap)

@@ -13,8 +13,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=gpurun_out/r03c
 mkdir -p $O
-B="bench.py --only-timed --no-cpu-baseline --steps 6 --warmup 2"   # bench.py's default workload: 1024 frames per launch
-B64="bench.py --only-timed --no-cpu-baseline --batch 64 --rotate 4 --steps 10 --warmup 2"  # BASELINE.json configs[2]
+B="bench.py --only-timed --no-cpu-baseline --steps 6 --warmup 4"  # (4 warm-up steps: the adaptive first pass re-partitions the tile rows after the second batch; pmc_to_json.py leaves them out)   # bench.py's default workload: 1024 frames per launch
+B64="bench.py --only-timed --no-cpu-baseline --batch 64 --rotate 4 --steps 10 --warmup 4"  # BASELINE.json configs[2]
 run() {  # name, rocprof args..., -- bench args
   local name=$1; shift
   echo "== $name: $*" >> $O/log.txt
@@ -44,7 +44,7 @@ run fast4_fetch --kernel-trace --pmc FETCH_SIZE -d $O/fast4_fetch -o run --outpu
 run fast4_write --kernel-trace --pmc WRITE_SIZE -d $O/fast4_write -o run --output-format csv -- python3 $B --full-work
 unset ORBX_FAST_IMPL
 # kernel durations at 64 frames per launch (BASELINE.json configs[2]; pools inside the Infinity Cache) and at 256
-B256="bench.py --only-timed --no-cpu-baseline --batch 256 --rotate 2 --steps 10 --warmup 2"
+B256="bench.py --only-timed --no-cpu-baseline --batch 256 --rotate 2 --steps 10 --warmup 4"
 for cfg in timed fullwork unfused; do
   case $cfg in
     timed) X="";;
@@ -55,8 +55,8 @@ for cfg in timed fullwork unfused; do
   run b256_${cfg}_stats --kernel-trace --stats -d $O/b256_${cfg}_stats -o run --output-format csv -- python3 $B256 $X
 done
 # BASELINE.json configs[4]: 1920x1080, 12 levels, 4000 features
-run hd_timed_stats --kernel-trace --stats -d $O/hd_timed_stats -o run --output-format csv -- python3 bench.py --workload 1080p --batch 32 --rotate 2 --steps 6 --warmup 1 --only-timed --no-cpu-baseline
-run hd_fullwork_stats --kernel-trace --stats -d $O/hd_fullwork_stats -o run --output-format csv -- python3 bench.py --workload 1080p --batch 32 --rotate 2 --steps 6 --warmup 1 --only-timed --no-cpu-baseline --full-work
+run hd_timed_stats --kernel-trace --stats -d $O/hd_timed_stats -o run --output-format csv -- python3 bench.py --workload 1080p --batch 32 --rotate 2 --steps 6 --warmup 4 --only-timed --no-cpu-baseline
+run hd_fullwork_stats --kernel-trace --stats -d $O/hd_fullwork_stats -o run --output-format csv -- python3 bench.py --workload 1080p --batch 32 --rotate 2 --steps 6 --warmup 4 --only-timed --no-cpu-baseline --full-work
 # plain bench lines (no profiler): the default line, configs[2] (64 frames per step), configs[3] at N = 1
 # (8 x 1000-frame stream walked once), configs[4]
 python3 bench.py > $O/bench_default.json 2>> $O/log.txt || echo "FAILED bench_default" >> $O/log.txt
@@ -73,5 +73,6 @@ if [ -x tools/bw_probe.bin ]; then
     run calib_write_$mb --kernel-trace --pmc WRITE_SIZE -d $O/calib_write_$mb -o run --output-format csv -- ./tools/bw_probe.bin $mb
   done
 fi
-python3 tools/pmc_to_json.py $O profiles/r03 1024 > $O/summary.txt 2>&1 || true
+python3 tools/pmc_to_json.py $O profiles/r03 1024 4 > $O/summary.txt 2>&1 || true
+mkdir -p $O/profiles_r03 && cp profiles/r03/*.csv profiles/r03/*.json profiles/r03/*.txt $O/profiles_r03/ 2>/dev/null || true
 tail -5 $O/summary.txt

@@ -3,7 +3,7 @@
   *_kernel_stats.csv   per-kernel duration statistics (from the kernel traces)
   pmc_counters.json    per-kernel counters per STEP + the FETCH_SIZE / WRITE_SIZE calibration, stamped
                        with the hash of the kernel sources (bench.py uses it only for the same sources)
-usage: pmc_to_json.py <collect dir> <profiles dir>"""
+usage: pmc_to_json.py <collect dir> <profiles dir> [frames per launch] [warm-up steps to leave out]"""
 import collections
 import csv
 import glob
@@ -22,28 +22,58 @@ def kname(s):
 STEP_KERNEL = "k_level_select"  # launched exactly once per step (batch): its dispatch count = steps of a run
 
 
+SKIP_STEPS = 0  # warm-up steps of every run (argv[4]): their dispatches are left out -- the adaptive first pass
+# re-partitions the FAST tile rows after the second batch (orbx_api.cpp, adapt_tile_rows)
+
+
+def drop_warmup(rows, steps):
+    """rows: a kernel's dispatches in dispatch order; drops the first SKIP_STEPS steps' share of them"""
+    if not steps or SKIP_STEPS <= 0 or steps <= SKIP_STEPS or len(rows) % steps:
+        return rows, steps
+    per = len(rows) // steps
+    return rows[SKIP_STEPS * per:], steps - SKIP_STEPS
+
+
 def trace_stats(d):
     """kernel -> (calls, mean us, min us, max us, us per step) from a *_kernel_trace.csv.  A step of the
     production pipeline launches k_pyrblur and k_fast3 TWICE (top rows first): `us per step` sums them."""
-    out = collections.defaultdict(list)
+    raw = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "*kernel_trace.csv")):
         for r in csv.DictReader(open(f)):
-            out[kname(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    steps = len(out.get(STEP_KERNEL, [])) or None
-    return {k: (len(v), sum(v) / len(v), min(v), max(v), sum(v) / steps if steps else sum(v) / len(v)) for k, v in out.items()}
+            raw[kname(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    steps_all = len(raw.get(STEP_KERNEL, [])) or None
+    out, steps = {}, steps_all
+    for k, v in raw.items():
+        rows, st = drop_warmup([x[1] for x in sorted(v)], steps_all)
+        out[k] = rows
+        if k == STEP_KERNEL:
+            steps = st
+    if steps_all and steps == steps_all and SKIP_STEPS > 0 and steps_all > SKIP_STEPS:
+        steps = steps_all - SKIP_STEPS
+    def per_step(k, v):
+        # (a kernel whose dispatches could not be split by step keeps all of them: divide by all steps)
+        return sum(v) / (steps if len(v) != len(raw[k]) or not SKIP_STEPS else steps_all) if steps_all else sum(v) / len(v)
+    return {k: (len(v), sum(v) / len(v), min(v), max(v), per_step(k, v)) for k, v in out.items() if v}
 
 
 def counters(d, per_step=True):
     """kernel -> counter -> mean per STEP (sum over the kernel's dispatches / steps of the run); per dispatch
     for runs without the step kernel (the calibration probes)"""
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    raw = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            agg[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    steps = 0
-    if per_step and STEP_KERNEL in agg:
-        steps = max(len(x) for x in agg[STEP_KERNEL].values())
-    return {k: {c: (sum(x) / steps if steps else sum(x) / len(x)) for c, x in v.items()} for k, v in agg.items()}
+            raw[kname(r["Kernel_Name"])][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    steps_all = 0
+    if per_step and STEP_KERNEL in raw:
+        steps_all = max(len(x) for x in raw[STEP_KERNEL].values())
+    out = {}
+    for k, v in raw.items():
+        out[k] = {}
+        for c, x in v.items():
+            vals = [y[1] for y in sorted(x)]
+            rows, st = drop_warmup(vals, steps_all) if per_step else (vals, 0)
+            out[k][c] = sum(rows) / st if st else sum(rows) / len(rows)
+    return out
 
 
 def main():
@@ -52,6 +82,8 @@ def main():
     import bench
 
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+    global SKIP_STEPS
+    SKIP_STEPS = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     res = {"source_sha": bench.kernel_source_sha(), "batch": batch,
            "workload": "bench.py default: KITTI 1241x376, 8 levels, %d frames per launch" % batch,
            "kernels": {}, "configs": {}}

@@ -993,9 +993,11 @@ bool adapt_tile_rows(orbx_ctx* c) {
     const int cur = c->bm_fast.tile_h[l];
     if (hh >= orbx_fast3_tile_h(c->p.nms_window / 2) || c->plan.L[l].h <= top * hh) hh = 0;  // the default rows do
     want[l] = hh;
-    const int eff = hh ? hh : orbx_fast3_tile_h(c->p.nms_window / 2);
+    const int dflt = orbx_fast3_tile_h(c->p.nms_window / 2);
+    const int eff = hh ? hh : dflt, asked = c->tile_h_pref[l] ? c->tile_h_pref[l] : dflt;
     if (eff > cur) grow = true;                 // the first pass is too short for this stream: always follow
-    else if (eff + 2 < cur) change = true;      // shrink only for a gain of three rows or more
+    else if (eff + 2 < std::min(cur, asked)) change = true;  // shrink only for a gain of three rows or more (`cur`
+    // may be taller than what was asked for: a level never has more tile rows than the level above)
   }
   if (!grow && !change) return false;
   if (!grow && c->retiles >= 4 && c->need_window < 32) return false;  // (settle first)
