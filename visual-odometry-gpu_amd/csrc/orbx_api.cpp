@@ -989,15 +989,17 @@ bool adapt_tile_rows(orbx_ctx* c) {
       continue;
     }
     const int rows = (int)need + std::max(4, (int)need / 10);  // margin: the next frames' caps may fill a little lower
+    // the default tile rows of the level (make_bandmap: <= dflt rows, balanced)
+    const int dflt = orbx_fast3_tile_h(c->p.nms_window / 2), lh = c->plan.L[l].h;
+    const int bal = (lh + (lh + dflt - 1) / dflt - 1) / ((lh + dflt - 1) / dflt);
     int hh = (rows + top - 1) / top;
-    const int cur = c->bm_fast.tile_h[l];
-    if (hh >= orbx_fast3_tile_h(c->p.nms_window / 2) || c->plan.L[l].h <= top * hh) hh = 0;  // the default rows do
+    if (hh >= bal || lh <= top * hh) hh = 0;  // the default rows do
     want[l] = hh;
-    const int dflt = orbx_fast3_tile_h(c->p.nms_window / 2);
-    const int eff = hh ? hh : dflt, asked = c->tile_h_pref[l] ? c->tile_h_pref[l] : dflt;
-    if (eff > cur) grow = true;                 // the first pass is too short for this stream: always follow
-    else if (eff + 2 < std::min(cur, asked)) change = true;  // shrink only for a gain of three rows or more (`cur`
-    // may be taller than what was asked for: a level never has more tile rows than the level above)
+    const int eff = hh ? hh : bal, cur = c->bm_fast.tile_h[l], asked = c->tile_h_pref[l] ? c->tile_h_pref[l] : bal;
+    if (eff > cur) grow = true;  // the first pass has become too short for this stream: always follow
+    // shrink only for a gain of three rows or more (`cur` may be taller than what was asked for: a level never has
+    // more tile rows than the level above)
+    else if (eff + 2 < std::min(cur, asked)) change = true;
   }
   if (!grow && !change) return false;
   if (!grow && c->retiles >= 4 && c->need_window < 32) return false;  // (settle first)

@@ -788,7 +788,8 @@ __global__ __launch_bounds__(LVL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 //       k_lvl_rank     (64 candidates, level, frame)    4 threads per candidate
 //     Same arithmetic, same order, same tie rule: results are identical.
 __global__ __launch_bounds__(256) void k_lvl_compact(OrbxPlan plan, const u64* __restrict__ mask,
-                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ ncand) {
+                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ ncand,
+                                                     uint32_t* __restrict__ need) {
   __shared__ int s_wsum[4][4];
   const int l = blockIdx.x, f = blockIdx.y;
   const OrbxLevel& L = plan.L[l];
@@ -840,6 +841,9 @@ __global__ __launch_bounds__(256) void k_lvl_compact(OrbxPlan plan, const u64* _
     __syncthreads();
   }
   if (tid == 0) ncand[f * plan.nlevels + l] = base < cap ? base : cap;
+  // rows the level needed to fill its cap, for the adaptive first pass (see k_level_select; out[] was written by
+  // this workgroup before the loop's last barrier)
+  if (need && tid == 0 && cap > 0) atomicMax(&need[l], base >= cap ? (out[cap - 1] >> 16) + 1u : (uint32_t)L.h);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_lvl_harris(
@@ -1723,8 +1727,8 @@ hipError_t orbx_launch_level_select_auto(hipStream_t s, const OrbxPlan& plan, in
                       (force >= 0 ? force != 0 : maxcap > LVL_THREADS);  // more than one candidate per thread
   if (!spread)
     return orbx_launch_level_select(s, plan, n_frames, mode, d_mask, d_pyr, d_gauss, window, k, d_sel_lkp,
-                                    d_sel_resp, d_sel_count, d_need);  // (the spread kernels do not report)
-  hipLaunchKernelGGL(k_lvl_compact, dim3(plan.nlevels, n_frames), dim3(256), 0, s, plan, d_mask, d_cand, d_ncand);
+                                    d_sel_resp, d_sel_count, d_need);
+  hipLaunchKernelGGL(k_lvl_compact, dim3(plan.nlevels, n_frames), dim3(256), 0, s, plan, d_mask, d_cand, d_ncand, d_need);
   hipLaunchKernelGGL(k_lvl_harris, dim3((maxcap + 255) / 256, plan.nlevels, n_frames), dim3(256), 0, s, plan, d_pyr,
                      d_gauss, window, k, d_cand, d_ncand, d_cresp);
   const size_t lds = (size_t)((maxcap + 7) & ~7) * 8;
