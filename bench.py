@@ -641,7 +641,7 @@ def main():
                 e.update(extra)
             return e
 
-        fast_kernel = "k_fast4" if os.environ.get("ORBX_FAST_IMPL") == "4" else "k_fast3"
+        fast_kernel = "k_fast3" if os.environ.get("ORBX_FAST_IMPL") == "3" else "k_fast4"  # (the library's default: the streaming kernel)
         work_frac = fast_tiles[0] / max(fast_tiles[1], 1)
         pyr_frac = pyr_done[0] / max(pyr_done[1], 1)
         fused = not args.unfused

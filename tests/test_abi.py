@@ -112,7 +112,7 @@ def test_no_result_altering_environment_switch_in_the_shipping_library():
         "ORBX_FUSE",           # 0: pyramid and blur as two kernels instead of one
         "ORBX_PYR_GROUP",      # frames per dispatch group of the fused kernel (tests/test_batch64_parity.py)
         "ORBX_FAST_CHUNK",     # tiles per FAST workgroup (tests/test_batch64_parity.py)
-        "ORBX_FAST_IMPL",      # 4: register-streaming FAST kernel instead of the LDS tile kernel (both parity modules run both)
+        "ORBX_FAST_IMPL",      # 3: LDS tile FAST kernel instead of the register-streaming one (both parity modules run both)
         "ORBX_TOP_ROWS",       # FAST tile rows of the first pass of the top-rows-first pipeline, 0: one pass (same test)
     }
     assert found <= allowed, sorted(found - allowed)

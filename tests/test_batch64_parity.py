@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["3", "4"], ids=["fast-tiles", "fast-stream"])
 def fast_impl(request, monkeypatch):
     """Every test of this module runs with both FAST kernels of the whole path: the LDS tile kernel (orbx_fast.hip,
-    the default) and the register-streaming one (orbx_fast4.hip); ORBX_FAST_IMPL is read when a context is created."""
+    the stage operators') and the register-streaming one (orbx_fast4.hip, the whole path's default); ORBX_FAST_IMPL is read when a context is created."""
     monkeypatch.setenv("ORBX_FAST_IMPL", request.param)
     return request.param
 

@@ -222,7 +222,7 @@ def test_adaptive_first_pass_changes_the_tile_rows_not_the_results(pkg, batches2
             c.batch_device(d[i & 1].data_ptr(), n, W, H)
             compare(c.batch_fetch(0, n, cap), oracle256[i & 1][:n])
             totals.append(c.fast_tile_counts()[1])
-        assert totals[0] == 272 * n  # the default table (test_fast_tile_counts)
+        assert totals[0] in (272 * n, 146 * n)  # the default table of either FAST kernel (test_fast_tile_counts)
         assert totals[-1] > totals[0], totals  # shorter tile rows: more tiles
         learned = totals[-1]
         c.set_pipelined_batches(True)

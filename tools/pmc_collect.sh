@@ -4,7 +4,7 @@
 #   /opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots"); the program after `--` is python3 itself.
 # Configurations of bench.py (--only-timed: nothing but the timed region runs, so the per-kernel averages
 # describe exactly that configuration):
-#   timed      production: pyramid+blur fused, FAST early exit on
+#   timed      production: pyramid+blur fused, FAST (k_fast4) early exit on
 #   fullwork   FAST with every tile working (--full-work)
 #   unfused    separate pyramid and blur kernels (--unfused)
 set -e
@@ -35,13 +35,15 @@ for cfg in timed fullwork unfused; do
   run ${cfg}_fetch --kernel-trace --pmc FETCH_SIZE -d $O/${cfg}_fetch -o run --output-format csv -- python3 $B $X
   run ${cfg}_write --kernel-trace --pmc WRITE_SIZE -d $O/${cfg}_write -o run --output-format csv -- python3 $B $X
 done
-# the register-streaming FAST kernel (ORBX_FAST_IMPL=4; the default whole path runs the LDS tile kernel), every tile working
-export ORBX_FAST_IMPL=4
-run fast4_stats --kernel-trace --stats -d $O/fast4_stats -o run --output-format csv -- python3 $B --full-work
-run fast4_sqa --kernel-trace --pmc $SQA -d $O/fast4_sqa -o run --output-format csv -- python3 $B --full-work
-run fast4_sqb --kernel-trace --pmc $SQB -d $O/fast4_sqb -o run --output-format csv -- python3 $B --full-work
-run fast4_fetch --kernel-trace --pmc FETCH_SIZE -d $O/fast4_fetch -o run --output-format csv -- python3 $B --full-work
-run fast4_write --kernel-trace --pmc WRITE_SIZE -d $O/fast4_write -o run --output-format csv -- python3 $B --full-work
+# the LDS tile FAST kernel (ORBX_FAST_IMPL=3; the default whole path runs the register-streaming kernel), every tile
+# working, and in production
+export ORBX_FAST_IMPL=3
+run fast3_stats --kernel-trace --stats -d $O/fast3_stats -o run --output-format csv -- python3 $B --full-work
+run fast3_sqa --kernel-trace --pmc $SQA -d $O/fast3_sqa -o run --output-format csv -- python3 $B --full-work
+run fast3_sqb --kernel-trace --pmc $SQB -d $O/fast3_sqb -o run --output-format csv -- python3 $B --full-work
+run fast3_fetch --kernel-trace --pmc FETCH_SIZE -d $O/fast3_fetch -o run --output-format csv -- python3 $B --full-work
+run fast3_write --kernel-trace --pmc WRITE_SIZE -d $O/fast3_write -o run --output-format csv -- python3 $B --full-work
+run fast3timed_stats --kernel-trace --stats -d $O/fast3timed_stats -o run --output-format csv -- python3 $B
 unset ORBX_FAST_IMPL
 # kernel durations at 64 frames per launch (BASELINE.json configs[2]; pools inside the Infinity Cache) and at 256
 B256="bench.py --only-timed --no-cpu-baseline --batch 256 --rotate 2 --steps 10 --warmup 4"
@@ -61,7 +63,7 @@ run hd_fullwork_stats --kernel-trace --stats -d $O/hd_fullwork_stats -o run --ou
 # (8 x 1000-frame stream walked once), configs[4]
 python3 bench.py > $O/bench_default.json 2>> $O/log.txt || echo "FAILED bench_default" >> $O/log.txt
 python3 bench.py --batch 64 --rotate 4 --no-cpu-baseline > $O/bench_batch64.json 2>> $O/log.txt || echo "FAILED bench_batch64" >> $O/log.txt
-ORBX_FAST_IMPL=4 python3 bench.py --no-cpu-baseline --strong-frames 0 > $O/bench_fast4.json 2>> $O/log.txt || echo "FAILED bench_fast4" >> $O/log.txt
+ORBX_FAST_IMPL=3 python3 bench.py --no-cpu-baseline --strong-frames 0 > $O/bench_fast3.json 2>> $O/log.txt || echo "FAILED bench_fast3" >> $O/log.txt
 python3 bench.py --workload 1080p --batch 32 --rotate 2 --steps 10 --no-cpu-baseline > $O/bench_1080p.json 2>> $O/log.txt || echo "FAILED bench_1080p" >> $O/log.txt
 echo "bench lines done"
 # FETCH_SIZE / WRITE_SIZE calibration on known byte counts, per access width (tools/bw_probe.hip)

@@ -36,7 +36,7 @@ def drop_warmup(rows, steps):
 
 def trace_stats(d):
     """kernel -> (calls, mean us, min us, max us, us per step) from a *_kernel_trace.csv.  A step of the
-    production pipeline launches k_pyrblur and k_fast3 TWICE (top rows first): `us per step` sums them."""
+    production pipeline launches k_pyrblur and the FAST kernel TWICE (top rows first): `us per step` sums them."""
     raw = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "*kernel_trace.csv")):
         for r in csv.DictReader(open(f)):
@@ -87,7 +87,7 @@ def main():
     res = {"source_sha": bench.kernel_source_sha(), "batch": batch,
            "workload": "bench.py default: KITTI 1241x376, 8 levels, %d frames per launch" % batch,
            "kernels": {}, "configs": {}}
-    for cfg in ("timed", "fullwork", "unfused", "fast4", "b64_timed", "b64_fullwork", "b64_unfused", "b256_timed", "b256_fullwork",
+    for cfg in ("timed", "fullwork", "unfused", "fast3", "fast3timed", "b64_timed", "b64_fullwork", "b64_unfused", "b256_timed", "b256_fullwork",
                 "b256_unfused", "hd_timed", "hd_fullwork"):
         st = trace_stats(os.path.join(src, cfg + "_stats"))
         if not st:
@@ -120,8 +120,8 @@ def main():
         return res["configs"].get(cfg, {}).get("counters", {}).get(full_name(cfg, kern), {}).get(key)
 
     table = {"k_pyrblur": ("timed", "k_pyrblur"), "k_pyrblur_every_row": ("fullwork", "k_pyrblur"),
-             "k_fast3": ("timed", "k_fast3"), "k_fast3_full_work": ("fullwork", "k_fast3"),
-             "k_fast4_full_work": ("fast4", "k_fast4"), "k_level_select": ("timed", "k_level_select"),
+             "k_fast4": ("timed", "k_fast4"), "k_fast4_full_work": ("fullwork", "k_fast4"),
+             "k_fast3_full_work": ("fast3", "k_fast3"), "k_level_select": ("timed", "k_level_select"),
              "k_describe2": ("timed", "k_describe2"), "k_pyramid2": ("unfused", "k_pyramid2"),
              "k_blur3": ("unfused", "k_blur3")}
     for name, (cfg, kern) in table.items():
@@ -140,7 +140,7 @@ def main():
             e["traffic_bytes"] = (2.0 * fe + wr) * 1024.0
         res["kernels"][name] = e
     json.dump(res, open(os.path.join(dst, "pmc_counters.json"), "w"), indent=1, sort_keys=True)
-    for name in ("bench_default", "bench_batch64", "bench_fast4", "bench_1080p", "bw_probe_97", "bw_probe_1600"):
+    for name in ("bench_default", "bench_batch64", "bench_fast3", "bench_1080p", "bw_probe_97", "bw_probe_1600"):
         for ext in (".json", ".txt"):
             f = os.path.join(src, name + ext)
             if os.path.exists(f) and os.path.getsize(f) > 0:

@@ -196,7 +196,7 @@ struct orbx_ctx {
   int timing = 0;  // 0 off, 1 all stages, 2 blur + fast only
   int fast_early = 1;
   int blur_impl = 2;  // ORBX_BLUR_IMPL, read at creation (launch_blur_auto)
-  int fast_impl = 3;  // 3: LDS tile kernel (orbx_fast.hip), 4: streaming kernel (orbx_fast4.hip); ORBX_FAST_IMPL, read at creation
+  int fast_impl = 4;  // 4: streaming kernel (orbx_fast4.hip, the default), 3: LDS tile kernel (orbx_fast.hip); ORBX_FAST_IMPL, read at creation
   int fuse = 1;  // pyramid + blur in one kernel when blur runs on every level (orbx_set_fused_pyramid_blur)
   // Top-rows-first pipeline (enqueue_batch): 0 never, 1 whenever eligible, 2 adaptive -- the second pass
   // counts the (frame, level)s it skipped / had to produce (d_feedback, running totals, written to the pinned
@@ -547,12 +547,15 @@ int top_rows_env() {
   return v < 0 ? 0 : v;
 }
 
-// ORBX_FAST_IMPL=4: the whole path runs the register-streaming kernel (orbx_fast4.hip) instead of the LDS tile kernel
-// (orbx_fast.hip).  Same results, same speed within ~2 % on the benchmark stream (profiles/r03: 12 % fewer vector
-// instructions, but 14 instead of 24 waves per CU); read when a context is created (A/B timing in one process).
+// Which FAST + NMS kernel the whole path runs: the register-streaming kernel (orbx_fast4.hip; the default) or, with
+// ORBX_FAST_IMPL=3, the LDS tile kernel (orbx_fast.hip; always the stage operators').  Same results.  With every tile
+// working they take the same time (+-2 %: 6.5 % fewer vector instructions against 14 instead of 24 waves per CU);
+// in production -- the short tile rows of the adaptive first pass, most units exiting early -- the streaming kernel
+// has less to do per unit (no tile fill, no barriers): same-box A/B 519 k vs 499 k frames/s (tools/ab_fast2.sh).
+// Read when a context is created (A/B timing in one process).
 int fast_impl_env() {
   const char* e = getenv("ORBX_FAST_IMPL");
-  return e && atoi(e) == 4 ? 4 : 3;
+  return e && atoi(e) == 3 ? 3 : 4;
 }
 
 int build_plan(const orbx_params& p, int w0, int h0, OrbxPlan* plan, std::string* why, int fast_impl = 3) {
