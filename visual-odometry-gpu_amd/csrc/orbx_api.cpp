@@ -997,9 +997,11 @@ bool adapt_tile_rows(orbx_ctx* c) {
     const int bal = (lh + (lh + dflt - 1) / dflt - 1) / ((lh + dflt - 1) / dflt);
     int hh = (rows + top - 1) / top;
     if (hh >= bal || lh <= top * hh) hh = 0;  // the default rows do
-    want[l] = hh;
     const int eff = hh ? hh : bal, cur = c->bm_fast.tile_h[l], asked = c->tile_h_pref[l] ? c->tile_h_pref[l] : bal;
-    if (eff > cur) grow = true;  // the first pass has become too short for this stream: always follow
+    // (a level that neither must grow nor gains three rows keeps its height when another level makes the tables change)
+    want[l] = ((eff > cur && (int)need > top * cur) || eff + 2 < std::min(cur, asked)) ? hh : c->tile_h_pref[l];
+    // the first pass has become too short for this stream -- caps fill BELOW it (the margin is used up): follow
+    if (eff > cur && (int)need > top * cur) grow = true;
     // shrink only for a gain of three rows or more (`cur` may be taller than what was asked for: a level never has
     // more tile rows than the level above)
     else if (eff + 2 < std::min(cur, asked)) change = true;
