@@ -233,7 +233,9 @@ int orbx_fast_tile_counts(orbx_ctx* ctx, long long* worked, long long* total);
  * row-major order up to the cap (src/orb_cpu.cpp:108-110, src/orb.cpp:63), so nothing below is ever read.
  * Results are identical in every mode.  mode 0: never (one pass), 1: whenever eligible, 2 (default): adaptive
  * -- the second pass reports how many levels it could skip, and while that is less than a quarter the batches
- * run in one pass (with a probe every 128th batch). */
+ * run in one pass (with a probe every 128th batch); and the DEPTH of the first pass follows the stream: the
+ * selection reports in which row each level's cap filled, and the FAST tile rows of the level are sized so that
+ * the first pass ends just below it (the work is re-partitioned a few times per stream; never a result changes). */
 int orbx_set_top_rows_first(orbx_ctx* ctx, int mode);
 
 /* Pipelined batches (default off).  With enable = 1, consecutive orbx_detect_and_compute_batch_device calls on the
