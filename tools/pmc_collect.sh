@@ -68,7 +68,7 @@ python3 bench.py --workload 1080p --batch 32 --rotate 2 --steps 10 --no-cpu-base
 echo "bench lines done"
 # FETCH_SIZE / WRITE_SIZE calibration on known byte counts, per access width (tools/bw_probe.hip)
 [ -x tools/bw_probe.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/bw_probe.bin tools/bw_probe.hip >> $O/log.txt 2>&1 || true
-if [ -x tools/bw_probe.bin ]; then
+if [ -x tools/bw_probe.bin ] && [ -z "$SKIP_CALIB" ]; then  # (SKIP_CALIB=1: the probes do not depend on the library; keep the last calibration)
   for mb in 97 1600; do
     ./tools/bw_probe.bin $mb > $O/bw_probe_$mb.txt 2>&1
     run calib_fetch_$mb --kernel-trace --pmc FETCH_SIZE -d $O/calib_fetch_$mb -o run --output-format csv -- ./tools/bw_probe.bin $mb

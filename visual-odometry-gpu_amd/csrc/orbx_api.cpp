@@ -996,6 +996,14 @@ bool adapt_tile_rows(orbx_ctx* c) {
     const int dflt = orbx_fast3_tile_h(c->p.nms_window / 2), lh = c->plan.L[l].h;
     const int bal = (lh + (lh + dflt - 1) / dflt - 1) / ((lh + dflt - 1) / dflt);
     int hh = (rows + top - 1) / top;
+    // the streaming FAST kernel walks whole groups of 7 centre rows (tile rows + 2 x NMS radius): a height that is
+    // one or two rows into a new group gives them back where at least 3 rows of margin remain (measured: level 0 at
+    // 40 instead of 41 rows, FAST -4.6 %, pyramid -2.9 %; rounding every level to a group boundary costs more than
+    // it saves)
+    if (c->fast_impl == 4) {
+      const int over = (hh + 2 * (c->p.nms_window / 2)) % 7;
+      if ((over == 1 || over == 2) && top * (hh - over) >= (int)need + 3) hh -= over;
+    }
     if (hh >= bal || lh <= top * hh) hh = 0;  // the default rows do
     const int eff = hh ? hh : bal, cur = c->bm_fast.tile_h[l], asked = c->tile_h_pref[l] ? c->tile_h_pref[l] : bal;
     // (a level that neither must grow nor gains three rows keeps its height when another level makes the tables change)
