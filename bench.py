@@ -702,7 +702,7 @@ def main():
                        "sharding": "frame-parallel, no data-path collective",
                        "fast_early_exit": not args.full_work, "pyramid_blur_fused": not args.unfused,
                        "pyramid_top_rows_first": bool(pyr_done[0] < pyr_done[1]), "pipelined_batches": pipelined},
-            "roofline": {"bound": "hbm", "kernel": "k_blur3 (stand-alone)" if dom == "blur_alone" else fast_kernel + " (every tile working)",
+            "roofline": {"bound": "hbm", "kernel": "k_blur3 (stand-alone)" if dom == "blur_alone" else fast_kernel + (" (every tile working)" if fast_kernel == "k_fast3" else " (every unit working)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": kern.get(dom, {}).get("hbm_traffic_bytes_per_launch"),
                          "algorithmic_bytes_per_launch": alg["blur"] if dom == "blur_alone" else alg["fast_nms"],
